@@ -1,0 +1,110 @@
+/* nanorev.h - C-ABI of libnanorev_hip.so, the MI355X (gfx950) engine behind NanoReviser's
+ * window reviser (model1 + model2).
+ *
+ * The reference has no FFI for this path; the seam it exposes is the pair of Keras callables
+ * built by nanorevutils/output_handeler.py:206-255 (get_model1) and :258-307 (get_model2),
+ *     Model(inputs=[signal_input (B,T,50,1) f32, read_input (B,T,6) f32], outputs=[(B,C) softmax])
+ * (:250-251, :302-303), which NanoReviser.py:129-130 constructs per read and would call as
+ * `model.predict([signal_x, read_x])`.  Each entry point below cites the reference interface
+ * it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer adds on the reference
+ * side.
+ *
+ * Conventions: plain pointers and sizes only.  Every function returns 0 on success and a
+ * negative nrv_status otherwise; nothing throws.  The engine copies weights at create time and
+ * never keeps a caller pointer past the return of a call.  One handle per (process, GPU); calls
+ * on one handle are not re-entrant.  There is NO CPU fallback: without a usable HIP device
+ * nrv_create fails with NRV_E_NO_DEVICE.
+ */
+#ifndef NANOREV_H
+#define NANOREV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nrv_handle nrv_handle;
+
+typedef enum {
+  NRV_OK = 0,
+  NRV_E_INVALID = -1,    /* bad argument (null pointer, negative size, unsupported T) */
+  NRV_E_WEIGHTS = -2,    /* weight blob does not have the size the graph requires */
+  NRV_E_NO_DEVICE = -3,  /* no HIP device / device index out of range */
+  NRV_E_HIP = -4,        /* a HIP runtime call failed; see nrv_last_error */
+  NRV_E_NOMEM = -5
+} nrv_status;
+
+#define NRV_BACKEND_HIP 1
+
+/* Flat little-endian f32 blob holding the 60 tensors of one model in Keras' positional
+ * `load_weights` order (what `model.load_weights(<S>_win13_50ep_model{1,2}.h5)` would read;
+ * path convention NanoReviser.py:191-193; order SURVEY.md Appendix A-11). */
+typedef struct {
+  const float* data;
+  int64_t n_f32;
+} nrv_weights;
+
+/* Replaces get_model1()/get_model2() + load_weights (output_handeler.py:206-307;
+ * NanoReviser.py:129-130).  T = window length (SENT_LEN, output_handeler.py:201; the shipped
+ * weights are T=11).  recurrent_act: 0 = hard_sigmoid (Keras 2.2.4 default, what the weights
+ * were trained with), 1 = sigmoid (Keras >= 2.3 behaviour, enviroment/NanoReviser_macOS.yaml). */
+int nrv_create(const nrv_weights* model1, const nrv_weights* model2, int T, int device,
+               int recurrent_act, nrv_handle** out);
+
+void nrv_destroy(nrv_handle* h);
+
+/* Replaces model1.predict([signal, read]) and model2.predict([signal, read])
+ * (output_handeler.py:250-251, :302-303) on n independent windows.
+ *   signal [n][T][50] f32, read [n][T][6] f32 (feature order nanorevtrainutils.py:169).
+ *   p1 [n][6], p2 [n][5] softmax outputs; a1, a2 [n] argmax (ties -> lowest index).
+ * Any output pointer may be NULL.  All pointers are HOST memory. */
+int nrv_predict(nrv_handle* h, const float* signal, const float* read, int64_t n,
+                float* p1, float* p2, int8_t* a1, int8_t* a2);
+
+/* Whole-read form: the sliding windows x[i:i+T], i in [0, N-T) of
+ * nanorevtrainutils.py:198-209 are formed on the device and the signal branch runs once per
+ * event instead of once per (window, timestep).
+ *   sig_ev [N][50] f32, feat_ev [N][6] f32; outputs have N-T rows (0 rows if N <= T). */
+int nrv_predict_read(nrv_handle* h, const float* sig_ev, const float* feat_ev, int64_t N,
+                     float* p1, float* p2, int8_t* a1, int8_t* a2);
+
+/* Same two calls with DEVICE pointers, enqueued on the handle's stream without a host sync
+ * (call nrv_sync, or synchronise the stream you passed to nrv_set_stream). */
+int nrv_predict_device(nrv_handle* h, const float* d_signal, const float* d_read, int64_t n,
+                       float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2);
+int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d_feat_ev,
+                            int64_t N, float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2);
+
+/* Windows per internal launch group (Keras' predict(batch_size=...)); default 4096. */
+int nrv_set_batch(nrv_handle* h, int batch_windows);
+int nrv_get_batch(nrv_handle* h);
+
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+int nrv_set_stream(nrv_handle* h, void* hip_stream);
+int nrv_sync(nrv_handle* h);
+
+/* Per-kernel timing with HIP events recorded on the launch stream.  While enabled every
+ * launch group is bracketed by events; nrv_prof_read synchronises, adds up the elapsed times
+ * since the last read and returns, per kernel slot, total milliseconds and launch count.
+ * Slots: 0 cnn, 1 lstm1, 2 lstm2, 3 lstm3, 4 lstm4, 5 head. */
+#define NRV_N_KERNELS 6
+int nrv_prof_enable(nrv_handle* h, int on);
+int nrv_prof_read(nrv_handle* h, double* ms_total /*[NRV_N_KERNELS]*/,
+                  int64_t* launches /*[NRV_N_KERNELS]*/);
+const char* nrv_kernel_name(int slot);
+
+/* Message of the last failure on this handle (or, with h == NULL, of the last failed
+ * nrv_create on this thread).  Never NULL. */
+const char* nrv_last_error(nrv_handle* h);
+
+/* Always NRV_BACKEND_HIP: the library has no other backend. */
+int nrv_backend(nrv_handle* h);
+
+/* Window length the handle was created with. */
+int nrv_window(nrv_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOREV_H */

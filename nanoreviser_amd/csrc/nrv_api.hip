@@ -1,0 +1,579 @@
+// nrv_api.hip - host side of libnanorev_hip.so: weight packing, workspace, launch sequence and
+// the C-ABI declared in include/nanorev.h.  gfx950 only; no CPU path.
+#include "../../include/nanorev.h"
+#include "nrv_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nrv;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+constexpr int kMaxT = kHeadMaxT;
+constexpr int kRowPad = 128;           // workspace rows are padded to a multiple of this
+
+// ---- tensor table of one model blob (Keras positional order) --------
+struct Blob {
+  const float* p;
+  std::vector<size_t> off;
+  const float* t(int i) const { return p + off[i]; }
+};
+
+static std::vector<size_t> tensor_sizes(int T, int C) {
+  std::vector<size_t> s;
+  auto bn = [&](size_t c) { for (int i = 0; i < 4; ++i) s.push_back(c); };
+  auto bil = [&](size_t d, size_t h) {
+    for (int i = 0; i < 2; ++i) { s.push_back(d * 4 * h); s.push_back(h * 4 * h); s.push_back(4 * h); }
+  };
+  s.push_back(24); s.push_back(8); bn(8);
+  s.push_back(192); s.push_back(8); bn(8);
+  bil(6, 16); bn(32);
+  bil(32, 64); bn(128);
+  s.push_back(400 * 64); s.push_back(64);
+  bil(192, 128); bn(256);
+  bil(256, 64);
+  s.push_back(128 * 128); s.push_back(128);
+  s.push_back(128 * 32); s.push_back(32);
+  s.push_back(32 * 6); s.push_back(6);
+  s.push_back((size_t)6 * T * 16); s.push_back(16);
+  s.push_back((size_t)16 * C); s.push_back(C);
+  return s;
+}
+
+static bool make_blob(const nrv_weights* w, int T, int C, Blob* b) {
+  auto sz = tensor_sizes(T, C);
+  size_t tot = 0;
+  b->off.clear();
+  for (size_t v : sz) { b->off.push_back(tot); tot += v; }
+  if (!w || !w->data || (size_t)w->n_f32 != tot) return false;
+  b->p = w->data;
+  return true;
+}
+
+// ---- B-fragment packing ---------------------------------------------------------------------
+// One packed k-group for one 32-column tile: dst[lane][j] = get(k = 8*kg + 4*(lane>>5) + j, lane&31)
+template <class G>
+static void pack_kgroup(float* dst, int kg, G get) {
+  for (int lane = 0; lane < 64; ++lane)
+    for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = get(8 * kg + 4 * (lane >> 5) + j, lane & 31);
+}
+
+// Bi-LSTM layer: [dir][hg][kg][gate][64][4] ; bias [dir][hg][gate][32]
+static void pack_lstm(const Blob& b, int base, int Kin, int H, std::vector<float>& wpack,
+                      std::vector<float>& bias) {
+  const int NG = (H + 31) / 32;
+  const int KG_IN = (Kin + 7) / 8, KG_REC = H / 8, KG = KG_IN + KG_REC;
+  wpack.assign((size_t)2 * NG * KG * 4 * 256, 0.f);
+  bias.assign((size_t)2 * NG * 4 * 32, 0.f);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);   // (Kin, 4H)
+    const float* U = b.t(base + dir * 3 + 1);   // (H, 4H)
+    const float* B = b.t(base + dir * 3 + 2);   // (4H)
+    for (int hg = 0; hg < NG; ++hg) {
+      for (int kg = 0; kg < KG; ++kg)
+        for (int g = 0; g < 4; ++g) {
+          float* dst = wpack.data() + ((((size_t)(dir * NG + hg) * KG + kg) * 4 + g) * 256);
+          pack_kgroup(dst, kg < KG_IN ? kg : kg - KG_IN, [&](int k, int c) -> float {
+            int u = hg * 32 + c;
+            if (u >= H) return 0.f;
+            if (kg < KG_IN) return k < Kin ? W[(size_t)k * 4 * H + g * H + u] : 0.f;
+            return U[(size_t)k * 4 * H + g * H + u];
+          });
+        }
+      for (int g = 0; g < 4; ++g)
+        for (int c = 0; c < 32; ++c) {
+          int u = hg * 32 + c;
+          bias[((size_t)(dir * NG + hg) * 4 + g) * 32 + c] = u < H ? B[g * H + u] : 0.f;
+        }
+    }
+  }
+}
+
+// Dense (K x N row-major) -> [ntile][kg][64][4], columns >= N zero
+static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
+  const int NT = (N + 31) / 32, KG = (K + 7) / 8;
+  out.assign((size_t)NT * KG * 256, 0.f);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int kg = 0; kg < KG; ++kg)
+      pack_kgroup(out.data() + ((size_t)nt * KG + kg) * 256, kg, [&](int k, int c) -> float {
+        int col = nt * 32 + c;
+        return (k < K && col < N) ? W[(size_t)k * N + col] : 0.f;
+      });
+}
+
+// Keras inference BatchNorm as scale/shift:  x*inv + (beta - mean*inv), inv = gamma/sqrt(var+eps)
+static void bn_fold(const float* g, const float* be, const float* mu, const float* var, int n,
+                    float* scale, float* shift) {
+  for (int i = 0; i < n; ++i) {
+    float inv = g[i] / std::sqrt(var[i] + 1e-3f);
+    scale[i] = inv;
+    shift[i] = be[i] - mu[i] * inv;
+  }
+}
+
+struct DevModel {
+  float* all = nullptr;       // one allocation holding every packed tensor of the model
+  size_t n = 0;
+  // offsets (floats) into `all`
+  size_t conv, dpack, dbias;
+  size_t l_w[4], l_b[4], l_s[4], l_h[4];
+  size_t d1p, d1b, d2p, d2b, mop, mob, fw, fb, ow, ob;
+  int C;
+};
+
+}  // namespace
+
+struct nrv_handle {
+  int device = 0, T = 0, act = 0, batch = 4096;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  DevModel dm[2];
+  // workspace (per model)
+  int cap_rows = 0;                // padded rows the workspace holds
+  float *S[2] = {0, 0}, *X1[2] = {0, 0}, *X2[2] = {0, 0}, *X3[2] = {0, 0};
+  // staging for the host-pointer entry points
+  float *d_sig = nullptr, *d_feat = nullptr, *d_p[2] = {0, 0};
+  int8_t* d_a[2] = {0, 0};
+  int geo[4] = {2, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
+  std::string err;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;   // groups of NRV_N_KERNELS+1 events
+  size_t ev_used = 0;
+  double prof_ms[NRV_N_KERNELS] = {0};
+  int64_t prof_n[NRV_N_KERNELS] = {0};
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return NRV_E_HIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
+  const int T = h->T;
+  DevModel& d = h->dm[mi];
+  d.C = C;
+  std::vector<float> host;
+  auto put = [&](const float* p, size_t n) {
+    size_t o = host.size();
+    host.insert(host.end(), p, p + n);
+    while (host.size() % 4) host.push_back(0.f);      // keep every tensor 16-byte aligned
+    return o;
+  };
+  // conv block (nanorevcnn.py:29-38): w1[k][o], b1, bn1 scale/shift, w2[k][c][o], b2, bn2 scale/shift
+  {
+    float cv[264];
+    memcpy(cv, b.t(0), 24 * 4);
+    memcpy(cv + 24, b.t(1), 8 * 4);
+    bn_fold(b.t(2), b.t(3), b.t(4), b.t(5), 8, cv + 32, cv + 40);
+    memcpy(cv + 48, b.t(6), 192 * 4);
+    memcpy(cv + 240, b.t(7), 8 * 4);
+    bn_fold(b.t(8), b.t(9), b.t(10), b.t(11), 8, cv + 248, cv + 256);
+    d.conv = put(cv, 264);
+  }
+  std::vector<float> wp, bs;
+  pack_dense(b.t(32), 400, 64, wp);
+  d.dpack = put(wp.data(), wp.size());
+  d.dbias = put(b.t(33), 64);
+  const int lbase[4] = {12, 22, 34, 44}, lK[4] = {6, 32, 192, 256}, lH[4] = {16, 64, 128, 64};
+  const int bnbase[4] = {18, 28, 40, -1};
+  for (int l = 0; l < 4; ++l) {
+    pack_lstm(b, lbase[l], lK[l], lH[l], wp, bs);
+    d.l_w[l] = put(wp.data(), wp.size());
+    d.l_b[l] = put(bs.data(), bs.size());
+    std::vector<float> sc(2 * lH[l], 1.f), sh(2 * lH[l], 0.f);
+    if (bnbase[l] >= 0)
+      bn_fold(b.t(bnbase[l]), b.t(bnbase[l] + 1), b.t(bnbase[l] + 2), b.t(bnbase[l] + 3), 2 * lH[l],
+              sc.data(), sh.data());
+    d.l_s[l] = put(sc.data(), sc.size());
+    d.l_h[l] = put(sh.data(), sh.size());
+  }
+  pack_dense(b.t(50), 128, 128, wp); d.d1p = put(wp.data(), wp.size());
+  d.d1b = put(b.t(51), 128);
+  pack_dense(b.t(52), 128, 32, wp); d.d2p = put(wp.data(), wp.size());
+  d.d2b = put(b.t(53), 32);
+  pack_dense(b.t(54), 32, 6, wp); d.mop = put(wp.data(), wp.size());
+  {
+    float mb[32] = {0};
+    memcpy(mb, b.t(55), 6 * 4);
+    d.mob = put(mb, 32);
+  }
+  d.fw = put(b.t(56), (size_t)6 * T * 16);
+  d.fb = put(b.t(57), 16);
+  d.ow = put(b.t(58), (size_t)16 * C);
+  d.ob = put(b.t(59), C);
+  d.n = host.size();
+  HIPCHK(h, hipMalloc(&d.all, d.n * sizeof(float)));
+  HIPCHK(h, hipMemcpy(d.all, host.data(), d.n * sizeof(float), hipMemcpyHostToDevice));
+  return NRV_OK;
+}
+
+static void free_workspace(nrv_handle* h) {
+  for (int m = 0; m < 2; ++m) {
+    (void)hipFree(h->S[m]); (void)hipFree(h->X1[m]); (void)hipFree(h->X2[m]); (void)hipFree(h->X3[m]);
+    (void)hipFree(h->d_p[m]); (void)hipFree(h->d_a[m]);
+    h->S[m] = h->X1[m] = h->X2[m] = h->X3[m] = h->d_p[m] = nullptr;
+    h->d_a[m] = nullptr;
+  }
+  (void)hipFree(h->d_sig); (void)hipFree(h->d_feat);
+  h->d_sig = h->d_feat = nullptr;
+  h->cap_rows = 0;
+}
+
+static int ensure_workspace(nrv_handle* h) {
+  const int T = h->T;
+  int rows = ((h->batch + kRowPad - 1) / kRowPad) * kRowPad;
+  if (rows <= h->cap_rows) return NRV_OK;
+  free_workspace(h);
+  const size_t tiles = rows / 32;
+  // event-major S needs (rows + T + 32) events; window-major S needs rows*T "events"
+  for (int m = 0; m < 2; ++m) {
+    size_t nS = (tiles * T + 2) * 16 * 128, n1 = tiles * T * 8 * 128, n2 = tiles * T * 32 * 128,
+           n3 = tiles * T * 64 * 128;
+    HIPCHK(h, hipMalloc(&h->S[m], nS * 4));
+    HIPCHK(h, hipMalloc(&h->X1[m], n1 * 4));
+    HIPCHK(h, hipMalloc(&h->X2[m], n2 * 4));
+    HIPCHK(h, hipMalloc(&h->X3[m], n3 * 4));
+    HIPCHK(h, hipMemset(h->S[m], 0, nS * 4));
+    HIPCHK(h, hipMemset(h->X1[m], 0, n1 * 4));
+    HIPCHK(h, hipMemset(h->X2[m], 0, n2 * 4));
+    HIPCHK(h, hipMemset(h->X3[m], 0, n3 * 4));
+    HIPCHK(h, hipMalloc(&h->d_p[m], (size_t)rows * 8 * 4));
+    HIPCHK(h, hipMalloc(&h->d_a[m], (size_t)rows));
+  }
+  HIPCHK(h, hipMalloc(&h->d_sig, (size_t)rows * T * kSig * 4 + 4096));
+  HIPCHK(h, hipMalloc(&h->d_feat, (size_t)rows * T * kFeat * 4 + 4096));
+  h->cap_rows = rows;
+  return NRV_OK;
+}
+
+// Wave geometry of a Bi-LSTM launch: R row tiles per wave, WR wave-rows per workgroup.
+struct Geo { int R, WR; };
+static const Geo kGeo[5] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}, {2, 2}};
+
+template <int KQ0, int KQ1, int H, bool PLAIN>
+static void launch_lstm(nrv_handle* h, const LstmArgs& a, int tiles, int geo) {
+  constexpr int NG = (H + 31) / 32;
+#define NRV_L(RR, WW, ACT)                                                                     \
+  hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, RR, WW, PLAIN, ACT>),                    \
+                     dim3((tiles + RR * WW - 1) / (RR * WW), 2, 2), dim3(64 * NG * WW), 0, h->stream, a)
+#define NRV_G(ACT)                                                                             \
+  switch (geo) {                                                                               \
+    case 1: NRV_L(2, 1, ACT); break;                                                           \
+    case 2: NRV_L(1, 2, ACT); break;                                                           \
+    case 3: NRV_L(1, 4, ACT); break;                                                           \
+    case 4: NRV_L(2, 2, ACT); break;                                                           \
+    default: NRV_L(1, 1, ACT); break;                                                          \
+  }
+  if (h->act == 0) { NRV_G(0) } else { NRV_G(1) }
+#undef NRV_G
+#undef NRV_L
+}
+
+// One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
+// n + T - 1 events and the windows are formed on the device.
+static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int n, bool read_mode,
+                     float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2) {
+  const int T = h->T;
+  const int tiles = (n + 31) / 32;
+  hipEvent_t* ev = nullptr;
+  if (h->prof) {
+    if (h->ev_used + NRV_N_KERNELS + 1 > h->ev_pool.size()) {
+      for (int i = 0; i < NRV_N_KERNELS + 1; ++i) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+      }
+    }
+    ev = h->ev_pool.data() + h->ev_used;
+    h->ev_used += NRV_N_KERNELS + 1;
+    HIPCHK(h, hipEventRecord(ev[0], h->stream));
+  }
+  auto mark = [&](int k) -> int {
+    if (ev) HIPCHK(h, hipEventRecord(ev[k], h->stream));
+    return NRV_OK;
+  };
+  int rc;
+
+  // 0: signal branch
+  {
+    CnnArgs a;
+    for (int m = 0; m < 2; ++m) {
+      const DevModel& d = h->dm[m];
+      a.m[m] = CnnModelParams{d.all + d.conv, d.all + d.dpack, d.all + d.dbias, h->S[m]};
+    }
+    a.signal = d_sig;
+    if (read_mode) { a.T = 1; a.n_rows = n + T - 1; }
+    else { a.T = T; a.n_rows = n; }
+    int blocks = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
+    hipLaunchKernelGGL(cnn_kernel, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+    if ((rc = mark(1))) return rc;
+  }
+  auto win_view = [&](const float* p, int kq) { return ActView{p, kq, 0, T, 1}; };
+  // 1..4: Bi-LSTM layers
+  {
+    LstmArgs a;
+    a.T = T; a.n_rows = n;
+    for (int m = 0; m < 2; ++m) {
+      const DevModel& d = h->dm[m];
+      a.m[m] = LstmModelParams{d.all + d.l_w[0], d.all + d.l_b[0], d.all + d.l_s[0], d.all + d.l_h[0],
+                               ActView{}, ActView{}, d_feat, read_mode ? 1 : 0, h->X1[m]};
+    }
+    launch_lstm<0, 0, 16, true>(h, a, tiles, h->geo[0]);
+    if ((rc = mark(2))) return rc;
+    for (int m = 0; m < 2; ++m) {
+      const DevModel& d = h->dm[m];
+      a.m[m] = LstmModelParams{d.all + d.l_w[1], d.all + d.l_b[1], d.all + d.l_s[1], d.all + d.l_h[1],
+                               win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
+    }
+    launch_lstm<8, 0, 64, false>(h, a, tiles, h->geo[1]);
+    if ((rc = mark(3))) return rc;
+    for (int m = 0; m < 2; ++m) {
+      const DevModel& d = h->dm[m];
+      ActView sv = read_mode ? ActView{h->S[m], 16, 1, 1, 0} : win_view(h->S[m], 16);
+      a.m[m] = LstmModelParams{d.all + d.l_w[2], d.all + d.l_b[2], d.all + d.l_s[2], d.all + d.l_h[2],
+                               win_view(h->X2[m], 32), sv, nullptr, 0, h->X3[m]};
+    }
+    launch_lstm<32, 16, 128, false>(h, a, tiles, h->geo[2]);
+    if ((rc = mark(4))) return rc;
+    for (int m = 0; m < 2; ++m) {
+      const DevModel& d = h->dm[m];
+      a.m[m] = LstmModelParams{d.all + d.l_w[3], d.all + d.l_b[3], d.all + d.l_s[3], d.all + d.l_h[3],
+                               win_view(h->X3[m], 64), ActView{}, nullptr, 0, h->X2[m] /* X4 aliases X2 */};
+    }
+    launch_lstm<64, 0, 64, false>(h, a, tiles, h->geo[3]);
+    if ((rc = mark(5))) return rc;
+  }
+  // 5: head
+  {
+    HeadArgs a;
+    a.T = T; a.n_rows = n;
+    float* dp[2] = {d_p1 ? d_p1 : h->d_p[0], d_p2 ? d_p2 : h->d_p[1]};
+    int8_t* da[2] = {d_a1 ? d_a1 : h->d_a[0], d_a2 ? d_a2 : h->d_a[1]};
+    for (int m = 0; m < 2; ++m) {
+      const DevModel& d = h->dm[m];
+      a.m[m] = HeadModelParams{d.all + d.d1p, d.all + d.d1b, d.all + d.d2p, d.all + d.d2b,
+                               d.all + d.mop, d.all + d.mob, d.all + d.fw, d.all + d.fb,
+                               d.all + d.ow, d.all + d.ob, h->X2[m], dp[m], da[m], d.C};
+    }
+    hipLaunchKernelGGL(head_kernel, dim3(tiles, 2), dim3(256), 0, h->stream, a);
+    if ((rc = mark(6))) return rc;
+  }
+  HIPCHK(h, hipGetLastError());
+  return NRV_OK;
+}
+
+static int prof_collect(nrv_handle* h) {
+  if (h->ev_used == 0) return NRV_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (size_t g = 0; g + NRV_N_KERNELS + 1 <= h->ev_used; g += NRV_N_KERNELS + 1)
+    for (int k = 0; k < NRV_N_KERNELS; ++k) {
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[g + k], h->ev_pool[g + k + 1]));
+      h->prof_ms[k] += ms;
+      h->prof_n[k] += 1;
+    }
+  h->ev_used = 0;
+  return NRV_OK;
+}
+
+static int check_handle(nrv_handle* h) {
+  if (!h) return NRV_E_INVALID;
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) { h->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return NRV_E_HIP; }
+  return NRV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, int recurrent_act,
+               nrv_handle** out) {
+  if (!out) { g_create_error = "nrv_create: out is NULL"; return NRV_E_INVALID; }
+  *out = nullptr;
+  if (T < 1 || T > kMaxT) { g_create_error = "nrv_create: window length T out of range [1,32]"; return NRV_E_INVALID; }
+  if (recurrent_act != 0 && recurrent_act != 1) { g_create_error = "nrv_create: recurrent_act must be 0 or 1"; return NRV_E_INVALID; }
+  Blob b1, b2;
+  if (!make_blob(m1, T, 6, &b1)) { g_create_error = "nrv_create: model1 blob size does not match the graph for this T (expect 6 classes)"; return NRV_E_WEIGHTS; }
+  if (!make_blob(m2, T, 5, &b2)) { g_create_error = "nrv_create: model2 blob size does not match the graph for this T (expect 5 classes)"; return NRV_E_WEIGHTS; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("nrv_create: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU fallback";
+    return NRV_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_create_error = "nrv_create: device index out of range"; return NRV_E_NO_DEVICE; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return NRV_E_HIP; }
+  nrv_handle* h = new (std::nothrow) nrv_handle();
+  if (!h) { g_create_error = "out of host memory"; return NRV_E_NOMEM; }
+  h->device = device; h->T = T; h->act = recurrent_act;
+  if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
+    int r[4];
+    if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)
+      for (int i = 0; i < 4; ++i) h->geo[i] = (r[i] >= 0 && r[i] < 5) ? r[i] : 0;
+  }
+  int rc = NRV_OK;
+  e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete h; return NRV_E_HIP; }
+  h->stream = h->own_stream;
+  if ((rc = upload_model(h, 0, b1, 6)) || (rc = upload_model(h, 1, b2, 5)) || (rc = ensure_workspace(h))) {
+    g_create_error = h->err;
+    nrv_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return NRV_OK;
+}
+
+void nrv_destroy(nrv_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_workspace(h);
+  for (int m = 0; m < 2; ++m) (void)hipFree(h->dm[m].all);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int nrv_set_batch(nrv_handle* h, int batch) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (batch < 1 || batch > (1 << 20)) { h->err = "nrv_set_batch: batch out of range"; return NRV_E_INVALID; }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->batch = batch;
+  return ensure_workspace(h);
+}
+int nrv_get_batch(nrv_handle* h) { return h ? h->batch : NRV_E_INVALID; }
+
+int nrv_set_stream(nrv_handle* h, void* s) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return NRV_OK;
+}
+
+int nrv_sync(nrv_handle* h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return NRV_OK;
+}
+
+int nrv_predict_device(nrv_handle* h, const float* d_signal, const float* d_read, int64_t n,
+                       float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!d_signal || !d_read))) { h->err = "nrv_predict_device: bad arguments"; return NRV_E_INVALID; }
+  const int T = h->T;
+  for (int64_t s = 0; s < n; s += h->batch) {
+    int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+    rc = run_group(h, d_signal + s * T * kSig, d_read + s * T * kFeat, nb, false,
+                   d_p1 ? d_p1 + s * 6 : nullptr, d_p2 ? d_p2 + s * 5 : nullptr,
+                   d_a1 ? d_a1 + s : nullptr, d_a2 ? d_a2 + s : nullptr);
+    if (rc) return rc;
+  }
+  return NRV_OK;
+}
+
+int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d_feat_ev, int64_t N,
+                            float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (N < 0 || (N > 0 && (!d_sig_ev || !d_feat_ev))) { h->err = "nrv_predict_read_device: bad arguments"; return NRV_E_INVALID; }
+  const int T = h->T;
+  const int64_t n = N - T;
+  for (int64_t s = 0; s < n; s += h->batch) {
+    int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+    rc = run_group(h, d_sig_ev + s * kSig, d_feat_ev + s * kFeat, nb, true,
+                   d_p1 ? d_p1 + s * 6 : nullptr, d_p2 ? d_p2 + s * 5 : nullptr,
+                   d_a1 ? d_a1 + s : nullptr, d_a2 ? d_a2 + s : nullptr);
+    if (rc) return rc;
+  }
+  return NRV_OK;
+}
+
+static int predict_host(nrv_handle* h, const float* sig, const float* feat, int64_t n_in, bool read_mode,
+                        float* p1, float* p2, int8_t* a1, int8_t* a2) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (n_in < 0 || (n_in > 0 && (!sig || !feat))) { h->err = "nrv_predict: bad arguments"; return NRV_E_INVALID; }
+  const int T = h->T;
+  const int64_t n = read_mode ? n_in - T : n_in;
+  for (int64_t s = 0; s < n; s += h->batch) {
+    int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+    size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
+    const float* hs = sig + (read_mode ? s * kSig : s * T * kSig);
+    const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
+    HIPCHK(h, hipMemcpyAsync(h->d_sig, hs, ev * kSig * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_feat, hf, ev * kFeat * 4, hipMemcpyHostToDevice, h->stream));
+    rc = run_group(h, h->d_sig, h->d_feat, nb, read_mode, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (p1) HIPCHK(h, hipMemcpyAsync(p1 + s * 6, h->d_p[0], (size_t)nb * 6 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (p2) HIPCHK(h, hipMemcpyAsync(p2 + s * 5, h->d_p[1], (size_t)nb * 5 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (a1) HIPCHK(h, hipMemcpyAsync(a1 + s, h->d_a[0], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+    if (a2) HIPCHK(h, hipMemcpyAsync(a2 + s, h->d_a[1], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffers are reused by the next group
+  }
+  return NRV_OK;
+}
+
+int nrv_predict(nrv_handle* h, const float* signal, const float* read, int64_t n, float* p1, float* p2,
+                int8_t* a1, int8_t* a2) {
+  return predict_host(h, signal, read, n, false, p1, p2, a1, a2);
+}
+
+int nrv_predict_read(nrv_handle* h, const float* sig_ev, const float* feat_ev, int64_t N, float* p1,
+                     float* p2, int8_t* a1, int8_t* a2) {
+  return predict_host(h, sig_ev, feat_ev, N, true, p1, p2, a1, a2);
+}
+
+int nrv_prof_enable(nrv_handle* h, int on) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = prof_collect(h))) return rc;
+  h->prof = on != 0;
+  return NRV_OK;
+}
+
+int nrv_prof_read(nrv_handle* h, double* ms_total, int64_t* launches) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = prof_collect(h))) return rc;
+  for (int k = 0; k < NRV_N_KERNELS; ++k) {
+    if (ms_total) ms_total[k] = h->prof_ms[k];
+    if (launches) launches[k] = h->prof_n[k];
+    h->prof_ms[k] = 0;
+    h->prof_n[k] = 0;
+  }
+  return NRV_OK;
+}
+
+const char* nrv_kernel_name(int slot) {
+  static const char* names[NRV_N_KERNELS] = {"cnn_kernel", "lstm_layer_kernel<lstm1 6->16>",
+                                             "lstm_layer_kernel<lstm2 32->64>",
+                                             "lstm_layer_kernel<lstm3 192->128>",
+                                             "lstm_layer_kernel<lstm4 256->64>", "head_kernel"};
+  return (slot >= 0 && slot < NRV_N_KERNELS) ? names[slot] : "";
+}
+
+const char* nrv_last_error(nrv_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int nrv_backend(nrv_handle* h) { (void)h; return NRV_BACKEND_HIP; }
+int nrv_window(nrv_handle* h) { return h ? h->T : NRV_E_INVALID; }
+
+}  // extern "C"

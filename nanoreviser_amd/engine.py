@@ -1,0 +1,250 @@
+"""ctypes binding of libnanorev_hip.so + the Keras-shaped facade the reference would call.
+
+The reference builds two Keras models per read (NanoReviser.py:129-130,
+output_handeler.py:206-307) whose public use is `model.predict([signal_x, read_x])`
+-> (B, C) softmax.  `Reviser` keeps that call shape:
+
+    rv = Reviser.from_species("ecoli")            # model/<S>/<S>_win13_50ep_model{1,2}
+    p1 = rv.model1.predict([signal_x, read_x])    # (B,6)   == get_model1().predict(...)
+    p2 = rv.model2.predict([signal_x, read_x])    # (B,5)   == get_model2().predict(...)
+    p1, p2, a1, a2 = rv.predict_pair(signal_x, read_x)
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+usable, construction raises (the caller's "fall back to the original bases" path of
+NanoReviser.py:146-152 is then what fires).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .weights import ModelWeights, load_species
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnanorev_hip.so")
+N_KERNELS = 6
+
+SYMBOLS = [
+    "nrv_create", "nrv_destroy", "nrv_predict", "nrv_predict_read", "nrv_predict_device",
+    "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
+    "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
+    "nrv_window",
+]
+
+
+class NrvError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libnanorev_hip: error {code}: {msg}")
+        self.code = code
+
+
+class _Weights(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_float)), ("n_f32", C.c_int64)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the engine.  Raises OSError loudly when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if ours
+    # (/opt/rocm) were loaded first and torch later, the process would hold two HSA runtimes and
+    # the second sees no GPU.  Importing torch first makes the dynamic linker resolve our
+    # NEEDED libamdhip64.so.7 to the copy torch already loaded.  (NRV_NO_TORCH=1 skips this.)
+    if os.environ.get("NRV_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    lib = C.CDLL(p)
+    fp, i8p, vp = C.POINTER(C.c_float), C.POINTER(C.c_int8), C.c_void_p
+    lib.nrv_create.argtypes = [C.POINTER(_Weights), C.POINTER(_Weights), C.c_int, C.c_int, C.c_int,
+                               C.POINTER(vp)]
+    lib.nrv_create.restype = C.c_int
+    lib.nrv_destroy.argtypes = [vp]
+    lib.nrv_destroy.restype = None
+    for name in ("nrv_predict", "nrv_predict_read"):
+        f = getattr(lib, name)
+        f.argtypes = [vp, fp, fp, C.c_int64, fp, fp, i8p, i8p]
+        f.restype = C.c_int
+    for name in ("nrv_predict_device", "nrv_predict_read_device"):
+        f = getattr(lib, name)
+        f.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+        f.restype = C.c_int
+    lib.nrv_set_batch.argtypes = [vp, C.c_int]
+    lib.nrv_get_batch.argtypes = [vp]
+    lib.nrv_set_stream.argtypes = [vp, vp]
+    lib.nrv_sync.argtypes = [vp]
+    lib.nrv_prof_enable.argtypes = [vp, C.c_int]
+    lib.nrv_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.nrv_kernel_name.argtypes = [C.c_int]
+    lib.nrv_kernel_name.restype = C.c_char_p
+    lib.nrv_last_error.argtypes = [vp]
+    lib.nrv_last_error.restype = C.c_char_p
+    lib.nrv_backend.argtypes = [vp]
+    lib.nrv_window.argtypes = [vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _as_f32(a, shape_tail):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim >= 1 and tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"expected trailing shape {shape_tail}, got {a.shape}")
+    return a
+
+
+class _ModelFacade:
+    """`.predict([signal, read])` of one of the two Keras models (output_handeler.py:250-251)."""
+
+    def __init__(self, owner: "Reviser", which: int):
+        self._o, self._w = owner, which
+
+    def predict(self, inputs: Sequence, batch_size: Optional[int] = None, verbose=0):
+        signal_x, read_x = inputs
+        return self._o._cached_pair(signal_x, read_x, batch_size)[self._w]
+
+
+class Reviser:
+    def __init__(self, model1: ModelWeights, model2: ModelWeights, device: int = 0,
+                 recurrent_activation: str = "hard_sigmoid", batch: int = 4096,
+                 lib_path: Optional[str] = None):
+        if model1.T != model2.T:
+            raise ValueError("model1/model2 window lengths differ")
+        if recurrent_activation not in ("hard_sigmoid", "sigmoid"):
+            raise ValueError("recurrent_activation must be 'hard_sigmoid' or 'sigmoid'")
+        self._lib = load_library(lib_path)
+        self.T = int(model1.T)
+        self._h = C.c_void_p()
+        f1, f2 = model1.flat(), model2.flat()
+        w1 = _Weights(f1.ctypes.data_as(C.POINTER(C.c_float)), f1.size)
+        w2 = _Weights(f2.ctypes.data_as(C.POINTER(C.c_float)), f2.size)
+        rc = self._lib.nrv_create(C.byref(w1), C.byref(w2), self.T, int(device),
+                                  0 if recurrent_activation == "hard_sigmoid" else 1,
+                                  C.byref(self._h))
+        if rc != 0:
+            raise NrvError(rc, self._lib.nrv_last_error(None).decode())
+        self.device = int(device)
+        if batch != 4096:
+            self.set_batch(batch)
+        self.model1 = _ModelFacade(self, 0)
+        self.model2 = _ModelFacade(self, 1)
+        self._cache_key = None
+        self._cache_val = None
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_species(cls, species: str = "ecoli", model_dir: Optional[str] = None, T: Optional[int] = None,
+                     **kw) -> "Reviser":
+        """NanoReviser.py:191-193: ./model/<S>/<S>_win13_50ep_model{1,2}.h5 (or the .f32 form)."""
+        m1, m2 = load_species(species, model_dir)
+        if T is not None and T != m1.T:
+            m1, m2 = m1.with_window(T), m2.with_window(T)
+        return cls(m1, m2, **kw)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise NrvError(rc, self._lib.nrv_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.nrv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ host-array API
+    def predict_pair(self, signal_x, read_x, batch_size: Optional[int] = None):
+        """Both models on n independent windows.  signal_x (n,T,50[,1]), read_x (n,T,6)."""
+        read_x = _as_f32(read_x, (self.T, 6))
+        n = read_x.shape[0]
+        signal_x = np.ascontiguousarray(signal_x, dtype=np.float32).reshape(n, self.T, 50)
+        if batch_size:
+            self.set_batch(int(batch_size))
+        p1 = np.empty((n, 6), np.float32)
+        p2 = np.empty((n, 5), np.float32)
+        a1 = np.empty(n, np.int8)
+        a2 = np.empty(n, np.int8)
+        fp, i8p = C.POINTER(C.c_float), C.POINTER(C.c_int8)
+        self._check(self._lib.nrv_predict(
+            self._h, signal_x.ctypes.data_as(fp), read_x.ctypes.data_as(fp), n,
+            p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p)))
+        return p1, p2, a1, a2
+
+    def predict_read(self, sig_ev, feat_ev):
+        """Whole read: per-event arrays (N,50), (N,6) -> outputs for the N-T sliding windows."""
+        sig_ev = _as_f32(sig_ev, (50,))
+        feat_ev = _as_f32(feat_ev, (6,))
+        N = feat_ev.shape[0]
+        if sig_ev.shape[0] != N:
+            raise ValueError("sig_ev / feat_ev length mismatch")
+        n = max(N - self.T, 0)
+        p1 = np.empty((n, 6), np.float32)
+        p2 = np.empty((n, 5), np.float32)
+        a1 = np.empty(n, np.int8)
+        a2 = np.empty(n, np.int8)
+        fp, i8p = C.POINTER(C.c_float), C.POINTER(C.c_int8)
+        self._check(self._lib.nrv_predict_read(
+            self._h, sig_ev.ctypes.data_as(fp), feat_ev.ctypes.data_as(fp), N,
+            p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p)))
+        return p1, p2, a1, a2
+
+    def _cached_pair(self, signal_x, read_x, batch_size):
+        key = (id(signal_x), id(read_x), np.shape(read_x))
+        if self._cache_key != key:
+            self._cache_val = self.predict_pair(signal_x, read_x, batch_size)
+            self._cache_key = key
+        return self._cache_val
+
+    # ------------------------------------------------------------------ device-pointer API
+    def predict_device(self, d_signal: int, d_read: int, n: int, d_p1: int = 0, d_p2: int = 0,
+                       d_a1: int = 0, d_a2: int = 0):
+        """Raw device pointers (ints), asynchronous on the handle's stream."""
+        self._check(self._lib.nrv_predict_device(self._h, d_signal, d_read, int(n), d_p1 or None,
+                                                 d_p2 or None, d_a1 or None, d_a2 or None))
+
+    def predict_read_device(self, d_sig_ev: int, d_feat_ev: int, N: int, d_p1: int = 0, d_p2: int = 0,
+                            d_a1: int = 0, d_a2: int = 0):
+        self._check(self._lib.nrv_predict_read_device(self._h, d_sig_ev, d_feat_ev, int(N), d_p1 or None,
+                                                      d_p2 or None, d_a1 or None, d_a2 or None))
+
+    def set_batch(self, batch: int):
+        self._check(self._lib.nrv_set_batch(self._h, int(batch)))
+
+    @property
+    def batch(self) -> int:
+        return int(self._lib.nrv_get_batch(self._h))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.nrv_set_stream(self._h, hip_stream or None))
+
+    def sync(self):
+        self._check(self._lib.nrv_sync(self._h))
+
+    def prof_enable(self, on: bool = True):
+        self._check(self._lib.nrv_prof_enable(self._h, 1 if on else 0))
+
+    def prof_read(self):
+        ms = (C.c_double * N_KERNELS)()
+        cnt = (C.c_int64 * N_KERNELS)()
+        self._check(self._lib.nrv_prof_read(self._h, ms, cnt))
+        return {self._lib.nrv_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(N_KERNELS)}
+
+    @property
+    def backend(self) -> str:
+        return {1: "hip"}[int(self._lib.nrv_backend(self._h))]
