@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""bench.py - bases revised / s of the MI355X reviser engine on BASELINE.json's workload.
+
+A "step" is one pass of the hot path (signal CNN + 4 Bi-LSTM + head, model1 AND model2) over one
+batch of 4096 synthetic independent 13-event windows per GPU (north_star target; generator:
+SURVEY.md 8d C4; E. coli weights + the seeded synthetic (78,16) `feature` kernel, because the
+shipped files are T=11 - SURVEY.md F3).  One window == one revised base.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Inputs are resident in HBM before the timed region.  Reads/windows are independent, so ranks own
+disjoint shards and the data path has NO collective (weak scaling); the only communication is the
+barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+
+The `cpu_baseline` leg (rank 0, N=1 only) times oracle/nrv_oracle.c - the plain-C f32 port, test
+infrastructure - on a bounded sample of the same windows, on the host cores.  It is a reported
+baseline, never the thing measured as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32 matrix)
+
+# MAC per (window, timestep, model): SURVEY.md 8a
+MAC_CNN = 1200 + 9600 + 25600
+MAC_L = {1: 2816, 2: 49152, 3: 327680, 4: 163840}
+MAC_HEAD_T = 16384 + 4096 + 192
+
+
+def flop_per_window(T):
+    """2 x (model1 + model2) MACs of one independent window (31 234 464 at T=13)."""
+    per_t = MAC_CNN + sum(MAC_L.values()) + MAC_HEAD_T
+    return 2 * ((per_t * T + 96 * T + 96) + (per_t * T + 96 * T + 80))
+
+
+def flop_lstm3_launch(T, n_windows, executed=True):
+    """FLOPs of ONE lstm3 launch (both directions, both models).  `executed`: the h_0 = 0 recurrent
+    product of the first step is not computed by the kernel, so it is not counted either."""
+    D, H = 192, 128
+    steps_rec = T - 1 if executed else T
+    mac = 2 * 4 * H * (T * D + steps_rec * H)           # two directions
+    return 2 * mac * 2 * n_windows                       # 2 FLOP/MAC, two models
+
+
+class Dist:
+    """One process per GPU; RCCL ('nccl') on GPUs, gloo for the CPU self-test."""
+
+    def __init__(self, backend):
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = dist if self.world > 1 else None
+        self.backend = backend
+        if self.dist is not None and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+
+    def _tensor(self, v, dtype):
+        import torch
+        dev = f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu"
+        return torch.tensor([v], dtype=dtype, device=dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_float(self, v):
+        import torch
+        if self.dist is None:
+            return float(v)
+        t = self._tensor(v, torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_int(self, v):
+        import torch
+        if self.dist is None:
+            return int(v)
+        t = self._tensor(v, torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def close(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def timed_steps(d, step_fn, sync_fn, steps, warmup):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides;
+    returns (max-over-ranks elapsed seconds, this rank's elapsed seconds)."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    d.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    mine = time.perf_counter() - t0
+    d.barrier()
+    return d.max_float(mine), mine
+
+
+def run_distributed_cpu_selftest(batch=4096, steps=3):
+    """CPU / gloo exercise of the N>1 control path (tests/test_shard_gloo.py): same Dist class,
+    same timed_steps, same shard arithmetic; the step itself is a sleep."""
+    from nanoreviser_amd import shard
+    d = Dist("gloo")
+    lo, hi = shard.shard_range(d.world * batch, d.rank, d.world)
+    done = {"n": 0}
+
+    def step():
+        time.sleep(0.01 * (d.rank + 1))
+        done["n"] += hi - lo
+
+    mx, mine = timed_steps(d, step, lambda: None, steps, 1)
+    total = d.sum_int((hi - lo) * steps)
+    d.close()
+    return {"total_units": total, "max_ms": mx * 1e3, "my_ms": mine * 1e3, "shard": (lo, hi)}
+
+
+def cpu_baseline(m1, m2, T, sig, rd, target_s=15.0):
+    """oracle/nrv_oracle.c on all host cores, bounded to ~target_s of CPU work."""
+    from oracle import c_oracle as CO
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:                                   # a cgroup CPU quota caps what the threads can really use
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    f1, f2 = m1.flat(), m2.flat()
+
+    def run(n):
+        t0 = time.perf_counter()
+        CO.predict(f1, T, 6, sig[:n], rd[:n], threads=cores)
+        CO.predict(f2, T, 5, sig[:n], rd[:n], threads=cores)
+        return time.perf_counter() - t0
+
+    n0 = min(len(rd), 8 * cores)
+    t_cal = run(n0)
+    n = int(min(len(rd), max(n0, n0 * target_s / max(t_cal, 1e-3))))
+    t = run(n)
+    if t < 0.5 * target_s and n == len(rd):          # whole step was too quick: repeat it
+        reps = int(min(64, max(1, target_s / max(t, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run(n)
+        t = time.perf_counter() - t0
+        n *= reps
+    ref = "unavailable on this host"
+    try:
+        import keras  # noqa: F401
+        import tensorflow  # noqa: F401
+        ref = "importable (not timed: bench uses the port)"
+    except Exception:
+        pass
+    return {"value": n / t, "unit": "bases/s", "cores": cores, "kind": "port",
+            "sample": f"{n} windows drawn from the step's {len(rd)} synthetic windows (T={T}), model1+model2, "
+                      f"oracle/nrv_oracle.c with {cores} OpenMP threads, {t:.1f} s",
+            "reference_keras_tf": ref}
+
+
+def load_traffic(T, batch):
+    """HBM bytes per lstm3 launch from the committed PMC pass (profiles/*.json), else None."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_lstm3.json")
+    try:
+        j = json.load(open(p))
+        if j.get("T") == T and j.get("batch") == batch:
+            return j.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
+    ap.add_argument("--window", type=int, default=13, help="events per window (T)")
+    ap.add_argument("--species", default="ecoli")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    from nanoreviser_amd.engine import Reviser
+    from nanoreviser_amd.weights import load_species
+    from oracle import nrv_oracle as O      # synthetic-window generator + smoke check only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    d = Dist("nccl")
+
+    T, B = args.window, args.batch
+    m1, m2 = load_species(args.species)
+    m1, m2 = m1.with_window(T), m2.with_window(T)
+    rv = Reviser(m1, m2, device=local_rank, batch=B)
+    stream = torch.cuda.current_stream()
+    rv.set_stream(stream.cuda_stream)
+
+    sig, rd = O.synth_windows(B, T, seed=20260 + d.rank)     # each rank owns its own shard
+    dev = f"cuda:{local_rank}"
+    d_sig, d_rd = torch.from_numpy(sig).to(dev), torch.from_numpy(rd).to(dev)
+    p1 = torch.empty(B, 6, device=dev)
+    p2 = torch.empty(B, 5, device=dev)
+    a1 = torch.empty(B, dtype=torch.int8, device=dev)
+    a2 = torch.empty(B, dtype=torch.int8, device=dev)
+    ptrs = (d_sig.data_ptr(), d_rd.data_ptr(), B, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
+
+    def step():
+        rv.predict_device(*ptrs)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    # correctness guard before timing anything: 64 windows against the fp64 oracle
+    step(); sync()
+    q1, q2, b1, b2 = O.predict_pair(m1.tensors, m2.tensors, sig[:64], rd[:64], np.float64)
+    dp = max(float(np.abs(p1[:64].cpu().numpy() - q1).max()), float(np.abs(p2[:64].cpu().numpy() - q2).max()))
+    if dp > 1e-4 or not (np.array_equal(a1[:64].cpu().numpy(), b1) and np.array_equal(a2[:64].cpu().numpy(), b2)):
+        sys.exit(f"bench.py: HIP path disagrees with the oracle (max|dp|={dp:.2e}); refusing to time it")
+
+    if not args.no_prof:
+        rv.prof_enable(True)
+        rv.prof_read()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.no_prof:
+        rv.prof_read()                                   # discard warm-up launches
+    elapsed, _ = timed_steps(d, step, sync, args.steps, 0)
+    prof = rv.prof_read() if not args.no_prof else {}
+    total = d.sum_int(B * args.steps)
+    value = total / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    out = {
+        "metric": "bases revised/sec (whole node)", "value": value, "unit": "bases/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.species} weights, synthetic independent {T}-event windows (SURVEY 8d C4 "
+                        f"generator), batch={B} windows per GPU per step, model1+model2"
+                        + ("; T=13 uses the shipped weights + seeded synthetic (78,16) feature kernel" if T != 11 else ""),
+            "species": args.species, "window": T, "batch_windows_per_gpu": B,
+            "parallelism": f"read/window-sharded x{args.gpus}, no collectives",
+            "parity_guard_max_abs_dp": dp,
+        },
+    }
+    if d.rank == 0:
+        if prof:
+            names = list(prof.keys())
+            per_kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in prof.items()}
+            k3 = names[3]
+            avg_s = prof[k3][0] / max(prof[k3][1], 1) * 1e-3
+            fl = flop_lstm3_launch(T, B, executed=True)
+            ach = fl / avg_s / 1e12
+            out["roofline"] = {
+                "kernel": k3, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": load_traffic(T, B),
+                "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": prof[k3][1],
+                "timing": "hipEvent pairs on the launch stream inside the timed region",
+            }
+            whole = flop_per_window(T) * B / (ms_per_step * 1e-3) / 1e12
+            out["roofline_whole_step"] = {"achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": whole / PEAK_F32_MFMA_TFLOPS,
+                                          "flop_per_window": flop_per_window(T)}
+            out["kernel_us"] = per_kernel_us
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(m1, m2, T, sig, rd)
+        print(json.dumps(out), flush=True)
+    rv.close()
+    d.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (ctypes -> libnanorev_hip.so),
+against the oracle and the committed goldens.  MI355X only (-m gpu).
+
+Bars (BASELINE.json north_star): per-base argmax identical; softmax probabilities within 1e-4 of
+the fp64 arbiter for E. coli.  For the human weights the fp32 noise floor itself is 2.1e-4 (both
+independent f32 restatements of the oracle sit there on one window, tests/test_oracle.py), so the
+bound is 5e-4 there and the measured maxima are recorded in DESIGN.md.
+"""
+import numpy as np
+import pytest
+
+from nanoreviser_amd import hoststage as hs
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"ecoli": 1e-4, "human": 5e-4}
+
+
+def assert_argmax(a, p_ref64, tol, what=""):
+    """argmax must equal the fp64 arbiter's, except on NEAR-TIES: windows where the arbiter's own
+    top-1 and the class the engine chose differ by <= 2*tol in probability, i.e. both calls are
+    correct to within the probability tolerance (minimum top-1/top-2 margins of
+    1.5e-4 occur with the human weights; the T=13 synthetic golden set holds one at 1.5e-6).
+    Returns the number of near-tie windows."""
+    ref = p_ref64.argmax(-1)
+    bad = np.nonzero(np.asarray(a) != ref)[0]
+    for i in bad:
+        gap = p_ref64[i, ref[i]] - p_ref64[i, int(a[i])]
+        assert gap <= 2 * tol, f"{what}: window {i}: engine class {int(a[i])} vs {ref[i]}, fp64 gap {gap:.2e}"
+    return len(bad)
+
+
+@pytest.fixture(scope="module")
+def engines(species_models):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from nanoreviser_amd.engine import Reviser
+    revs = {sp: Reviser(*species_models[sp]) for sp in species_models}
+    for rv in revs.values():
+        assert rv.backend == "hip"
+    yield revs
+    for rv in revs.values():
+        rv.close()
+
+
+def _windows(reads, key, T=11):
+    _, _, rt = reads(key)
+    sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, T)
+    return rt, sw, fw
+
+
+@pytest.mark.parametrize("sp", ["ecoli", "human"])
+def test_fixture_reads_vs_committed_fp64_goldens(engines, reads, model_goldens, sp):
+    rv = engines[sp]
+    worst, ties = 0.0, 0
+    for key in reads.keys:
+        _, sw, fw = _windows(reads, key)
+        idx = model_goldens[f"{key}/idx"]
+        p1, p2, a1, a2 = rv.predict_pair(np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx]))
+        d1 = np.abs(p1 - model_goldens[f"{key}/{sp}/p1"]).max()
+        d2 = np.abs(p2 - model_goldens[f"{key}/{sp}/p2"]).max()
+        worst = max(worst, d1, d2)
+        ties += assert_argmax(a1, model_goldens[f"{key}/{sp}/p1"], TOL[sp], key)
+        ties += assert_argmax(a2, model_goldens[f"{key}/{sp}/p2"], TOL[sp], key)
+        assert d1 <= TOL[sp] and d2 <= TOL[sp], (key, d1, d2)
+    if sp == "ecoli":
+        assert ties == 0
+    print(f"{sp}: near-tie argmax windows: {ties}")
+    print(f"{sp}: max |dp| vs fp64 goldens over 5 reads x 384 windows = {worst:.2e}")
+
+
+@pytest.mark.parametrize("sp", ["ecoli", "human"])
+def test_synthetic_goldens_T11_and_T13(species_models, model_goldens, sp):
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models[sp]
+    for T in (11, 13):
+        rv = Reviser(m1.with_window(T), m2.with_window(T))
+        sig, rd = model_goldens[f"synth{T}/signal"], model_goldens[f"synth{T}/read"]
+        p1, p2, a1, a2 = rv.predict_pair(sig, rd)
+        assert_argmax(a1, model_goldens[f"synth{T}/{sp}/p1"], TOL[sp], f"synth{T} m1")
+        assert_argmax(a2, model_goldens[f"synth{T}/{sp}/p2"], TOL[sp], f"synth{T} m2")
+        assert np.abs(p1 - model_goldens[f"synth{T}/{sp}/p1"]).max() <= TOL[sp]
+        assert np.abs(p2 - model_goldens[f"synth{T}/{sp}/p2"]).max() <= TOL[sp]
+        rv.close()
+
+
+def test_whole_read_live_oracle_and_read_mode(engines, reads, species_models):
+    """A full fixture read (6.6 k windows): window mode vs the live C oracle (f32) and NumPy fp64
+    on a slice; read mode (device-formed windows, per-event CNN) bit-identical to window mode."""
+    from oracle import c_oracle as CO
+    from oracle import nrv_oracle as O
+    rv = engines["ecoli"]
+    m1, m2 = species_models["ecoli"]
+    rt, sw, fw = _windows(reads, "ch10_read5252")
+    sw, fw = np.ascontiguousarray(sw), np.ascontiguousarray(fw)
+    p1, p2, a1, a2 = rv.predict_pair(sw, fw)
+    r1, r2, ra1, ra2 = rv.predict_read(rt.sig_ev, rt.feat_ev)
+    assert r1.shape == p1.shape == (len(rt.feat_ev) - 11, 6)
+    assert np.array_equal(p1, r1) and np.array_equal(p2, r2)
+    assert np.array_equal(a1, ra1) and np.array_equal(a2, ra2)
+    c1, ca1 = CO.predict(m1.flat(), 11, 6, sw, fw, threads=8)
+    c2, ca2 = CO.predict(m2.flat(), 11, 5, sw, fw, threads=8)
+    assert np.array_equal(a1, ca1) and np.array_equal(a2, ca2)
+    assert np.abs(p1 - c1).max() <= 1e-4 and np.abs(p2 - c2).max() <= 1e-4
+    sl = slice(3000, 3300)
+    q1, q2, b1, b2 = O.predict_pair(m1.tensors, m2.tensors, sw[sl], fw[sl], np.float64)
+    assert np.abs(p1[sl] - q1).max() <= 1e-4 and np.abs(p2[sl] - q2).max() <= 1e-4
+    assert np.array_equal(a1[sl], b1) and np.array_equal(a2[sl], b2)
+    # domain property: calls agree with the basecalls at the window centre
+    _, rd, _ = reads("ch10_read5252")
+    lab = np.array([hs.BASE_LABEL[b.decode()] for b in rd.bases])[5:5 + len(a1)]
+    assert (a1 == lab).mean() > 0.95 and (a2 + 1 == lab).mean() > 0.97
+
+
+def test_ragged_and_empty_inputs(engines, reads, species_models):
+    from oracle import c_oracle as CO
+    rv = engines["ecoli"]
+    m1, m2 = species_models["ecoli"]
+    rt, sw, fw = _windows(reads, "ch141_read5436")
+    ref1, refa1 = CO.predict(m1.flat(), 11, 6, np.ascontiguousarray(sw[:130]), np.ascontiguousarray(fw[:130]), threads=8)
+    base = rv.predict_pair(np.ascontiguousarray(sw[:130]), np.ascontiguousarray(fw[:130]))
+    assert np.abs(base[0] - ref1).max() <= 1e-4 and np.array_equal(base[2], refa1)
+    for n in (0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 129):
+        p1, p2, a1, a2 = rv.predict_pair(np.ascontiguousarray(sw[:n]), np.ascontiguousarray(fw[:n]))
+        assert p1.shape == (n, 6) and p2.shape == (n, 5) and a1.shape == (n,) and a2.shape == (n,)
+        # rows are independent: a prefix gives the same bits as the larger call
+        assert np.array_equal(p1, base[0][:n]) and np.array_equal(p2, base[1][:n])
+        assert np.array_equal(a1, base[2][:n]) and np.array_equal(a2, base[3][:n])
+    # read mode: N <= T yields no windows; N = T+1 yields one
+    for N in (0, 5, 11):
+        p1, p2, a1, a2 = rv.predict_read(rt.sig_ev[:N], rt.feat_ev[:N])
+        assert p1.shape == (0, 6) and a2.shape == (0,)
+    p1, _, a1, _ = rv.predict_read(rt.sig_ev[:12], rt.feat_ev[:12])
+    assert p1.shape == (1, 6) and np.array_equal(p1[0], base[0][0]) and a1[0] == base[2][0]
+
+
+def test_batch_grouping_is_invisible(reads, species_models):
+    """Keras predict(batch_size=...) must not change results: groups of 64/96/4096 windows."""
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["human"]
+    rt, sw, fw = _windows(reads, "ch13_read2251")
+    sw, fw = np.ascontiguousarray(sw[:1000]), np.ascontiguousarray(fw[:1000])
+    outs = []
+    for b in (4096, 96, 64):
+        rv = Reviser(m1, m2, batch=b)
+        assert rv.batch == b
+        outs.append(rv.predict_pair(sw, fw) + rv.predict_read(rt.sig_ev[:1011], rt.feat_ev[:1011]))
+        rv.close()
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)
+    # Keras-shaped facade: model1.predict / model2.predict
+    rv = Reviser(m1, m2)
+    assert np.array_equal(rv.model1.predict([sw[..., None], fw]), outs[0][0])
+    assert np.array_equal(rv.model2.predict([sw[..., None], fw], batch_size=512), outs[0][1])
+    rv.close()
+
+
+def test_sigmoid_variant_matches_oracle(reads, species_models):
+    """recurrent_act=1 (Keras >= 2.3 default, enviroment/NanoReviser_macOS.yaml) is a different
+    function; the engine implements it too and it must match the oracle's sigmoid variant."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["ecoli"]
+    _, sw, fw = _windows(reads, "ch117_read6465")
+    sw, fw = np.ascontiguousarray(sw[:200]), np.ascontiguousarray(fw[:200])
+    rv = Reviser(m1, m2, recurrent_activation="sigmoid")
+    p1, p2, a1, a2 = rv.predict_pair(sw, fw)
+    q1, q2, b1, b2 = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float64, recurrent_act="sigmoid")
+    assert np.abs(p1 - q1).max() <= 1e-4 and np.abs(p2 - q2).max() <= 1e-4
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+    h1 = O.forward(m1.tensors, sw, fw, np.float64)
+    assert np.abs(p1 - h1).max() > 1e-3          # and it is NOT the hard_sigmoid function
+    rv.close()
+
+
+def test_extreme_inputs_stay_finite(engines):
+    """Saturating gates, zero signal, huge features: no NaN/Inf, valid distributions."""
+    from oracle import nrv_oracle as O
+    rv = engines["ecoli"]
+    sig, rd = O.synth_windows(96, 11, seed=3)
+    sig[:32] = 0.0
+    rd[32:64] *= 50.0
+    sig[64:] = np.where(np.arange(50) % 2 == 0, 4.8, -8.4)
+    p1, p2, a1, a2 = rv.predict_pair(sig, rd)
+    for p in (p1, p2):
+        assert np.isfinite(p).all() and (p >= 0).all()
+        assert np.abs(p.sum(-1) - 1).max() < 1e-5
+    assert np.array_equal(a1, p1.argmax(-1)) and np.array_equal(a2, p2.argmax(-1))
+
+
+def test_full_size_properties_device_api(species_models):
+    """BASELINE sizes through the device-pointer entry points: 1 M synthetic 13-event windows in
+    groups of 4096 (configs[3]) and one 200 k-event read (configs[4]).  Size-independent properties:
+    determinism, permutation equivariance (rows independent), batch-grouping invariance,
+    probabilities sum to 1, argmax == argmax(prob), read mode == window mode."""
+    import torch
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["ecoli"]
+    T, n = 13, 1 << 20
+    rv = Reviser(m1.with_window(T), m2.with_window(T), batch=4096)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    sig = (torch.randn(n, T, 50, device="cuda", generator=g) * 1.36 - 0.10).clamp_(-8.4, 4.8)
+    feat = torch.rand(n, T, 6, device="cuda", generator=g)
+    feat[..., 4] = feat[..., 4] * 80 + 70
+    feat[..., 5] = feat[..., 5] * 10 + 1
+
+    def run(s, f, rvx):
+        k = s.shape[0]
+        p1 = torch.empty(k, 6, device="cuda"); p2 = torch.empty(k, 5, device="cuda")
+        a1 = torch.empty(k, dtype=torch.int8, device="cuda"); a2 = torch.empty(k, dtype=torch.int8, device="cuda")
+        rvx.predict_device(s.data_ptr(), f.data_ptr(), k, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
+        rvx.sync()
+        return p1, p2, a1, a2
+
+    o = run(sig, feat, rv)
+    o2 = run(sig, feat, rv)
+    for x, y in zip(o, o2):
+        assert torch.equal(x, y)                                   # deterministic
+    for p in o[:2]:
+        assert torch.isfinite(p).all() and (p.sum(-1) - 1).abs().max() < 1e-5
+    assert torch.equal(o[2].long(), o[0].argmax(-1)) and torch.equal(o[3].long(), o[1].argmax(-1))
+    perm = torch.randperm(n, device="cuda", generator=g)
+    op = run(sig[perm].contiguous(), feat[perm].contiguous(), rv)
+    for x, y in zip(o, op):
+        assert torch.equal(x[perm], y)                             # rows are independent
+    rv.set_batch(1000)                                             # ragged groups
+    sub = slice(0, 50_000)
+    ob = run(sig[sub].contiguous(), feat[sub].contiguous(), rv)
+    for x, y in zip(o, ob):
+        assert torch.equal(x[sub], y)
+    rv.close()
+
+    # one long read, streamed in device-formed window groups
+    N = 200_000
+    rv = Reviser(m1.with_window(T), m2.with_window(T), batch=4096)
+    sig_ev = (torch.randn(N, 50, device="cuda", generator=g) * 1.36 - 0.10).clamp_(-8.4, 4.8)
+    feat_ev = torch.rand(N, 6, device="cuda", generator=g)
+    k = N - T
+    p1 = torch.empty(k, 6, device="cuda"); p2 = torch.empty(k, 5, device="cuda")
+    a1 = torch.empty(k, dtype=torch.int8, device="cuda"); a2 = torch.empty(k, dtype=torch.int8, device="cuda")
+    rv.predict_read_device(sig_ev.data_ptr(), feat_ev.data_ptr(), N, p1.data_ptr(), p2.data_ptr(),
+                           a1.data_ptr(), a2.data_ptr())
+    rv.sync()
+    idx = torch.arange(0, 20_000, device="cuda")[:, None] + torch.arange(T, device="cuda")[None, :]
+    for base in (0, 100_000, k - 20_000):
+        w = run(sig_ev[idx + base].contiguous(), feat_ev[idx + base].contiguous(), rv)
+        assert torch.equal(w[0], p1[base:base + 20_000]) and torch.equal(w[1], p2[base:base + 20_000])
+        assert torch.equal(w[2], a1[base:base + 20_000]) and torch.equal(w[3], a2[base:base + 20_000])
+    rv.close()
