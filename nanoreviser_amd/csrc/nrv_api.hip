@@ -266,9 +266,13 @@ static const Geo kGeo[5] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}, {2, 2}};
 template <int KQ0, int KQ1, int H, bool PLAIN>
 static void launch_lstm(nrv_handle* h, const LstmArgs& a, int tiles, int geo) {
   constexpr int NG = (H + 31) / 32;
-#define NRV_L(RR, WW, ACT)                                                                     \
-  hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, RR, WW, PLAIN, ACT>),                    \
-                     dim3((tiles + RR * WW - 1) / (RR * WW), 2, 2), dim3(64 * NG * WW), 0, h->stream, a)
+  // at most 4 waves per workgroup (one per SIMD, 512 registers each): WR is clamped to 4/NG
+#define NRV_L(RR, WREQ, ACT)                                                                   \
+  {                                                                                            \
+    constexpr int WW = (NG * WREQ > 4) ? (4 / NG) : WREQ;                                      \
+    hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, RR, WW, PLAIN, ACT>),                  \
+                       dim3((tiles + RR * WW - 1) / (RR * WW), 2, 2), dim3(64 * NG * WW), 0, h->stream, a); \
+  }
 #define NRV_G(ACT)                                                                             \
   switch (geo) {                                                                               \
     case 1: NRV_L(2, 1, ACT); break;                                                           \

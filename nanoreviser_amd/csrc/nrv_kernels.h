@@ -47,6 +47,19 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// Buffer addressing: address = descriptor base (SGPR, wave-uniform) + per-lane voffset (VGPR, 32
+// bit) + soffset (SGPR / immediate).  Used for every streamed operand so that stepping through
+// k-groups is scalar arithmetic; with plain 64-bit pointers hipcc materialises (and spills) one
+// VGPR address pair per k-group.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
 // row of accumulator register `reg` for this lane (C/D map of the 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int reg, int lane) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -78,25 +91,29 @@ struct ActView {
     long off = ((long)((e >> 5) * tt + t * tm) * kq_total + kq) * 128 + (e & 31) * 4;
     return p + off;
   }
+  // Same address split for scalar-base addressing: chunk(rowbase + l31, t, half + kq) ==
+  // ubase(rowbase, t) + kq*128 + voff(rowbase, t, l31, half), with ubase wave-uniform (rowbase is)
+  // and voff a small per-lane offset (floats).
+  __device__ __forceinline__ const float* ubase(int rowbase, int t) const {
+    int eu = rowbase + t * ev_stride;
+    return p + ((long)((eu >> 5) * tt + t * tm) * kq_total) * 128;
+  }
+  __device__ __forceinline__ unsigned voff(int rowbase, int t, int l31, int half) const {
+    int x = ((rowbase + t * ev_stride) & 31) + l31;
+    return (unsigned)((x >> 5) * (tt * kq_total * 128) + (x & 31) * 4 + half * 128);
+  }
 };
 
 // ---------------------------------------------------------------------------------------
 // Bi-LSTM layer kernel
 // ---------------------------------------------------------------------------------------
-// tanh, branch-free.  |x| < 0.625: x + x^3 Q(x^2) (own degree-4 fit, rel. err 1.1e-7 in f32);
-// otherwise 1 - 2/(2^(2|x| log2 e) + 1) on the hardware exp2/rcp (1 ulp each).
+// tanh for the LSTM cell: 1 - 2/(2^(2x log2 e) + 1) on the hardware exp2/rcp (1 ulp each): five
+// instructions, no branch, exact limits at +-inf.  Absolute error <= ~1.5e-7 everywhere (for
+// |x| -> 0 the RELATIVE error grows, which is immaterial here: the argument is a 200-500-term f32
+// dot product whose own rounding noise is ~1e-6 absolute, and tanh' <= 1).
 __device__ __forceinline__ float tanh_fast(float x) {
-  const float ax = __builtin_fabsf(x);
-  const float u = x * x;
-  float q = -0.005731194745749235f;
-  q = __builtin_fmaf(q, u, 0.020664723590016365f);
-  q = __builtin_fmaf(q, u, -0.053748443722724915f);
-  q = __builtin_fmaf(q, u, 0.13331560790538788f);
-  q = __builtin_fmaf(q, u, -0.3333328664302826f);
-  const float small = __builtin_fmaf(ax * u, q, ax);
-  const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);   // exp(2|x|); +inf is fine
-  const float big = __builtin_fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
-  return __builtin_copysignf(ax < 0.625f ? small : big, x);
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return __builtin_fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
 }
 
 struct LstmModelParams {
@@ -123,10 +140,17 @@ struct LstmArgs {
 // R row tiles; a workgroup is NG x WR waves covering 32*R*WR rows.
 // grid = (ceil(tiles/(R*WR)), 2 directions, 2 models), block = 64*NG*WR.
 //
-// Per step the k-groups run as ONE software pipeline, recurrent groups first (A from the LDS image
-// of h_{t-1}), then the input groups (A from the tiled activations in global/L2); the fragments
-// of group g+1 are requested before the 16*R MFMAs of group g issue, so the L2 latency of the
-// weight stream hides under ~1000*R cycles of matrix work even at one wave per SIMD.
+// Schedule of one step s (time index t):
+//     Z  = b + x_t W            (already there: computed during step s-1)
+//     Z += h_{t-1} U            recurrent k-groups, A fragments from the LDS image of h_{t-1}
+//     N  = b + x_{t+1} W        input k-groups of the NEXT step - independent of h - issued on the
+//                               matrix pipe while the VALU turns Z into (c_t, h_t): the gate code
+//                               is cut into per-element pieces placed between MFMA sub-batches
+//     barrier; h_t (+BatchNorm) -> HBM; Z = N
+// so the only serial section is recurrent MFMAs -> last gate pieces -> barrier.  k-groups are
+// fully unrolled (static LDS/global address spaces, counted waits) and software-pipelined: the
+// fragments of group g+1 are requested before group g's 16*R MFMAs issue, and the first fragments
+// of each phase are requested one phase early.
 template <int KQ0, int KQ1, int H, int R, int WR, bool PLAIN_IN, int ACT>
 __global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
 lstm_layer_kernel(const LstmArgs args) {
@@ -139,13 +163,20 @@ lstm_layer_kernel(const LstmArgs args) {
   constexpr int PLANE = ROWS * 4 + 4;          // floats per kq plane (+4 pad: conflict-free writes)
   constexpr int HBUF = (HP / 4) * PLANE;       // floats per h buffer
   constexpr int NTHREADS = 64 * NG * WR;
+  // Prefetch depths in k-groups (one k-group = 16*R MFMAs = 1024*R cycles).  vmcnt retires in
+  // issue order, so each iteration requests the (L2-resident) weights first and the activations
+  // (Infinity-Cache / HBM latency) last: a wait for B(g) then leaves the younger A requests in flight.
+  constexpr int PB = (R == 1) ? 2 : 1;         // weight fragments:      PB groups ahead
+  constexpr int PA = PB + 1;                   // activation fragments:  PB+1 groups ahead
+  constexpr int NE = 16 * R;                   // gate elements per lane per step
+  constexpr int NSLOT = 4 * KG_IN;             // MFMA sub-batches of the input projection
   static_assert(H % 8 == 0, "H must be a multiple of 8");
   static_assert(PLAIN_IN || ((KQ0 % 2 == 0) && (KQ1 % 2 == 0)), "segments must be 8-aligned");
 
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
   const int hg = wave % NG;
   const int wr = wave / NG;
   const int half = lane >> 5;
@@ -153,130 +184,187 @@ lstm_layer_kernel(const LstmArgs args) {
   const int dir = blockIdx.y;
   const LstmModelParams& P = args.m[blockIdx.z];
   const int T = args.T;
-  const int row0 = blockIdx.x * ROWS + wr * (32 * R);     // first row of this wave
+  const int row0 = blockIdx.x * ROWS + wr * (32 * R);     // first row of this wave (uniform)
   const int lrow0 = wr * (32 * R);                         // same, block-local
 
-  const float* wp = P.wpack + ((size_t)(dir * NG + hg) * KG) * (4 * 64 * 4) + lane * 4;
+  // weights: wave-uniform base (SGPR pair) + per-lane 32-bit offset -> saddr addressing, so the
+  // k-group addresses are scalar adds instead of one 64-bit VGPR pair per group
+  const __amdgpu_buffer_rsrc_t wrs =
+      make_rsrc(P.wpack + ((size_t)(dir * NG + hg) * KG) * (4 * 64 * 4), KG * 4 * 64 * 4 * 4);
+  const unsigned wlane = lane * 16;                        // bytes
+  constexpr int WREC = KG_IN;                              // first recurrent k-group in the pack
   const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * 32 + l31;
-  const float bias_i = bp[0], bias_f = bp[32], bias_g = bp[64], bias_o = bp[96];
+  const float bias4[4] = {bp[0], bp[32], bp[64], bp[96]};
+  const int u = hg * 32 + l31;                             // hidden unit of this lane's column
+  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half) * 4;
+  const int hr_off = half * PLANE + (lrow0 + l31) * 4;
 
   f32x16 c[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
 
+  // ---- fragment loaders ---------------------------------------------------------------------
+  const float* ap0[R];                 // PLAIN_IN only: per-lane pointers
+  __amdgpu_buffer_rsrc_t ar0[R], ar1[R];  // tiled inputs: descriptors rebased per (step, row tile)
+  unsigned av0[R], av1[R];             // per-lane offsets (bytes)
+  auto set_t = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if constexpr (PLAIN_IN) {
+        const int row = row0 + r * 32 + l31;
+        ap0[r] = P.plain_in +
+                 (P.plain_ev_stride ? (size_t)(row + t) * kFeat : ((size_t)row * T + t) * kFeat) + 4 * half;
+      } else {
+        ar0[r] = make_rsrc(P.in0.ubase(row0 + r * 32, t), 0xffffffffu);
+        av0[r] = P.in0.voff(row0 + r * 32, t, l31, half) * 4;
+        if constexpr (KQ1 > 0) {
+          ar1[r] = make_rsrc(P.in1.ubase(row0 + r * 32, t), 0xffffffffu);
+          av1[r] = P.in1.voff(row0 + r * 32, t, l31, half) * 4;
+        }
+      }
+    }
+  };
+  auto loadA_in = [&](int kgi, f32x4 (&a)[R]) {
+    if constexpr (PLAIN_IN) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r * 32 + l31 < args.n_rows) {
+          v[0] = ap0[r][0];
+          v[1] = ap0[r][1];
+          if (!half) { v[2] = ap0[r][2]; v[3] = ap0[r][3]; }
+        }
+        a[r] = v;
+      }
+    } else if (KQ1 == 0 || kgi < KQ0 / 2) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = buf_load16(ar0[r], av0[r], kgi * 1024);
+    } else {
+      if constexpr (KQ1 > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = buf_load16(ar1[r], av1[r], (kgi - KQ0 / 2) * 1024);
+      }
+    }
+  };
+  auto loadB = [&](int kg, f32x4 (&b)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b[g] = buf_load16(wrs, wlane, (kg * 4 + g) * 1024);
+  };
+
+  // ---- one gate element: (row tile r, accumulator register reg) ---------------------------------
+  auto gate = [&](const f32x16 (&Z)[4][R], float* hw, int r, int reg) {
+    float ig = gate_act<ACT>(Z[0][r][reg]);
+    float fg = gate_act<ACT>(Z[1][r][reg]);
+    float gg = tanh_fast(Z[2][r][reg]);
+    float og = gate_act<ACT>(Z[3][r][reg]);
+    float cn = __builtin_fmaf(fg, c[r][reg], ig * gg);
+    c[r][reg] = cn;
+    hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = og * tanh_fast(cn);
+  };
+
+  // ---- N = b + x_t W, optionally with the gates of Z spread between the MFMA sub-batches ---------
+  auto preload = [&](f32x4 (&pa)[PA][R], f32x4 (&pb)[PB][4]) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      if (i < PB && i < KG_IN) loadB(i, pb[i]);
+      if (i < KG_IN) loadA_in(i, pa[i]);
+    }
+  };
+  auto inproj = [&](f32x16 (&N)[4][R], const f32x4 (&pa)[PA][R], const f32x4 (&pb)[PB][4], auto hook) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < R; ++r) N[g][r] = splat16(bias4[g]);
+    f32x4 a[PA + 1][R], b[PB + 1][4];
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[i][r] = pa[i][r];
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[i][g] = pb[i][g];
+#pragma unroll
+    for (int kg = 0; kg < KG_IN; ++kg) {
+      if (kg + PB < KG_IN) loadB(kg + PB, b[(kg + PB) % (PB + 1)]);
+      if (kg + PA < KG_IN) loadA_in(kg + PA, a[(kg + PA) % (PA + 1)]);
+      __builtin_amdgcn_sched_barrier(0);         // requests first; PB / PA k-groups of MFMAs cover them
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            N[g][r] = mfma32(a[kg % (PA + 1)][r][j], b[kg % (PB + 1)][g][j], N[g][r]);
+        hook(kg * 4 + j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  f32x16 acc[4][R];                      // the one accumulator set (matrix pipe)
+  f32x16 zv[4][R];                       // z of the current step, read out for the VALU
+  f32x4 preA[PA][R], preB[PB][4], brec0[4];
+
+  // prologue: acc = b + x_{t0} W
+  set_t(dir ? T - 1 : 0);
+  preload(preA, preB);
+  inproj(acc, preA, preB, [](int) {});
+
   for (int s = 0; s < T; ++s) {
     const int t = dir ? (T - 1 - s) : s;
     const float* hcur = hbuf + (s & 1) * HBUF;
     float* hnxt = hbuf + ((s + 1) & 1) * HBUF;
+    float* hw = hnxt + hw_off;
+    const bool more = s + 1 < T;
 
-    f32x16 acc[4][R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      acc[0][r] = splat16(bias_i);
-      acc[1][r] = splat16(bias_f);
-      acc[2][r] = splat16(bias_g);
-      acc[3][r] = splat16(bias_o);
+    if (more) {                                  // first fragments of the next input projection
+      set_t(dir ? t - 1 : t + 1);
+      preload(preA, preB);
     }
 
-    const float* ap0[R];
-    const float* ap1[R];
+    // ---- acc += h_{t-1} U   (h_0 = 0: nothing to add on the first step) -------------------------
+    if (s > 0) {
+      const float* hp = hcur + hr_off;
+      f32x4 a[2][R], b[2][4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if constexpr (PLAIN_IN) {
-        int row = row0 + r * 32 + l31;
-        ap0[r] = P.plain_in +
-                 (P.plain_ev_stride ? (size_t)(row + t) * kFeat : ((size_t)row * T + t) * kFeat) + 4 * half;
-        ap1[r] = nullptr;
-      } else {
-        ap0[r] = P.in0.chunk(row0 + r * 32 + l31, t, half);
-        if constexpr (KQ1 > 0) ap1[r] = P.in1.chunk(row0 + r * 32 + l31, t, half);
-        else ap1[r] = nullptr;
-      }
-    }
-    const float* hp = hcur + half * PLANE + (lrow0 + l31) * 4;
-
-    // fragment loaders; kgG: 0..KG_REC-1 recurrent, then the input groups
-    auto loadA = [&](int kgG, f32x4 (&a)[R]) {
-      if (kgG < KG_REC) {
+      for (int r = 0; r < R; ++r) a[0][r] = *(const f32x4*)(hp + r * 128);
 #pragma unroll
-        for (int r = 0; r < R; ++r) a[r] = *(const f32x4*)(hp + kgG * 2 * PLANE + r * 128);
-      } else {
-        const int kgi = kgG - KG_REC;
-        if constexpr (PLAIN_IN) {
+      for (int g = 0; g < 4; ++g) b[0][g] = brec0[g];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row0 + r * 32 + l31 < args.n_rows) {
-              v[0] = ap0[r][0];
-              v[1] = ap0[r][1];
-              if (!half) { v[2] = ap0[r][2]; v[3] = ap0[r][3]; }
-            }
-            a[r] = v;
-          }
-        } else if (KQ1 == 0 || kgi < KQ0 / 2) {
+      for (int kg = 0; kg < KG_REC; ++kg) {
+        const int cur = kg & 1;
+        if (kg + 1 < KG_REC) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) a[r] = *(const f32x4*)(ap0[r] + kgi * 256);
-        } else {
-#pragma unroll
-          for (int r = 0; r < R; ++r) a[r] = *(const f32x4*)(ap1[r] + (kgi - KQ0 / 2) * 256);
+          for (int r = 0; r < R; ++r) a[cur ^ 1][r] = *(const f32x4*)(hp + (kg + 1) * 2 * PLANE + r * 128);
+          loadB(WREC + kg + 1, b[cur ^ 1]);
         }
-      }
-    };
-    auto loadB = [&](int kgG, f32x4 (&b)[4]) {
-      const int kgw = kgG < KG_REC ? KG_IN + kgG : kgG - KG_REC;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) b[g] = *(const f32x4*)(wp + (kgw * 4 + g) * 256);
-    };
-    auto mma = [&](const f32x4 (&a)[R], const f32x4 (&b)[4]) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int r = 0; r < R; ++r) acc[g][r] = mfma32(a[r][j], b[g][j], acc[g][r]);
-    };
-
-    {
-      f32x4 a0[R], b0[4], a1[R], b1[4];
-      int kg = (s == 0) ? KG_REC : 0;            // h_0 = 0: the recurrent groups are skipped
-      loadA(kg, a0);
-      loadB(kg, b0);
-      for (; kg + 2 < KG; kg += 2) {
-        loadA(kg + 1, a1);
-        loadB(kg + 1, b1);
-        mma(a0, b0);
-        loadA(kg + 2, a0);
-        loadB(kg + 2, b0);
-        mma(a1, b1);
-      }
-      if (kg + 1 < KG) {
-        loadA(kg + 1, a1);
-        loadB(kg + 1, b1);
-        mma(a0, b0);
-        mma(a1, b1);
-      } else {
-        mma(a0, b0);
+            for (int r = 0; r < R; ++r) acc[g][r] = mfma32(a[cur][r][j], b[cur][g][j], acc[g][r]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
-    // ---- gates (register-local) and h_t -> LDS -------------------------------------------
-    {
-      const int u = hg * 32 + l31;                 // hidden unit of this lane's column
-      float* hw = hnxt + (u >> 2) * PLANE + (u & 3);
+    // ---- z -> VGPRs; gates of step s hidden under the input projection of step s+1 -----------------
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          float ig = gate_act<ACT>(acc[0][r][reg]);
-          float fg = gate_act<ACT>(acc[1][r][reg]);
-          float gg = tanh_fast(acc[2][r][reg]);
-          float og = gate_act<ACT>(acc[3][r][reg]);
-          float cn = __builtin_fmaf(fg, c[r][reg], ig * gg);
-          c[r][reg] = cn;
-          float hn = og * tanh_fast(cn);
-          hw[(lrow0 + r * 32 + acc_row(reg, lane)) * 4] = hn;
-        }
-      }
+      for (int r = 0; r < R; ++r) zv[g][r] = acc[g][r];
+    if (more) {
+      inproj(acc, preA, preB, [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+          if ((e * NSLOT) / NE == slot) gate(zv, hw, e / 16, e % 16);
+      });
+      loadB(WREC, brec0);                        // first recurrent weights of step s+1, ahead of the barrier
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) gate(zv, hw, e / 16, e % 16);
     }
     __syncthreads();
 

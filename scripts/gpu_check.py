@@ -47,7 +47,7 @@ for T in (13,):
     ds = torch.from_numpy(sig).cuda(); dr = torch.from_numpy(rd_).cuda()
     p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
     a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
-    for cfg in ("2,2,0,2", "2,2,1,2", "2,2,2,2", "3,3,4,3", "0,0,0,0"):
+    for cfg in ("2,2,0,2", "2,2,1,2", "3,2,0,2", "2,2,0,0", "2,2,1,4"):
         os.environ["NRV_GEO"] = cfg
         rv2 = Reviser(a, b)
         for it in range(3):
