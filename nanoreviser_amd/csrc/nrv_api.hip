@@ -140,6 +140,7 @@ struct nrv_handle {
   // staging for the host-pointer entry points
   float *d_sig = nullptr, *d_feat = nullptr, *d_p[2] = {0, 0};
   int8_t* d_a[2] = {0, 0};
+  int dbg = 0;                     // NRV_DBG timing experiments (never set in production)
   int geo[4] = {2, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
@@ -330,6 +331,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   {
     LstmArgs a;
     a.T = T; a.n_rows = n;
+    a.dbg = h->dbg;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
       a.m[m] = LstmModelParams{d.all + d.l_w[0], d.all + d.l_b[0], d.all + d.l_s[0], d.all + d.l_h[0],
@@ -425,6 +427,7 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   nrv_handle* h = new (std::nothrow) nrv_handle();
   if (!h) { g_create_error = "out of host memory"; return NRV_E_NOMEM; }
   h->device = device; h->T = T; h->act = recurrent_act;
+  if (const char* s = getenv("NRV_DBG")) h->dbg = atoi(s);
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
     int r[4];
     if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)

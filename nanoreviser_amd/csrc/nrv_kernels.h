@@ -133,6 +133,8 @@ struct LstmArgs {
   LstmModelParams m[2];
   int T;
   int n_rows;             // valid rows (windows)
+  int dbg;                // timing experiments only (NRV_DBG): 1 = all A reads from row tile 0,
+                          // 2 = no copy-out, 4 = no gates.  0 in production.
 };
 
 // KQ0/KQ1: input segments in 4-feature chunks (K = 4*KQ, K multiple of 8).  H: hidden units per
@@ -174,6 +176,7 @@ lstm_layer_kernel(const LstmArgs args) {
   static_assert(PLAIN_IN || ((KQ0 % 2 == 0) && (KQ1 % 2 == 0)), "segments must be 8-aligned");
 
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
+  __shared__ __attribute__((aligned(16))) float bnl[2 * H];     // BatchNorm scale | shift of this direction
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
@@ -202,6 +205,39 @@ lstm_layer_kernel(const LstmArgs args) {
   f32x16 c[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+  for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
+    bnl[i] = i < H ? P.bn_scale[dir * H + i] : P.bn_shift[dir * H + i - H];
+
+  // ---- h_t (+ fused BatchNorm) -> HBM: LDS image -> 16-byte coalesced stores.  Split in two so the
+  // LDS reads are issued ahead of, and the stores behind, the first recurrent MFMAs of the next step.
+  constexpr int KQH = H / 4;                   // real 4-feature chunks of this direction
+  constexpr int ITEMS = KQH * ROWS;            // float4 items per step
+  constexpr int NIT = (ITEMS + NTHREADS - 1) / NTHREADS;
+  f32x4 cov[NIT];
+  auto copyout_read = [&](const float* himg) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = threadIdx.x + i * NTHREADS;
+      if (ITEMS % NTHREADS == 0 || it < ITEMS) cov[i] = *(const f32x4*)(himg + (it / ROWS) * PLANE + (it % ROWS) * 4);
+    }
+  };
+  auto copyout_write = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = threadIdx.x + i * NTHREADS;
+      if (ITEMS % NTHREADS == 0 || it < ITEMS) {
+        const int kq = it / ROWS, rr = it % ROWS;
+        const f32x4 sc = *(const f32x4*)(bnl + kq * 4);
+        const f32x4 sh = *(const f32x4*)(bnl + H + kq * 4);
+        f32x4 v = cov[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
+        const int tile = blockIdx.x * (R * WR) + rr / 32;
+        float* dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
+        *(f32x4*)dst = v;
+      }
+    }
+  };
 
   // ---- fragment loaders ---------------------------------------------------------------------
   const float* ap0[R];                 // PLAIN_IN only: per-lane pointers
@@ -215,11 +251,12 @@ lstm_layer_kernel(const LstmArgs args) {
         ap0[r] = P.plain_in +
                  (P.plain_ev_stride ? (size_t)(row + t) * kFeat : ((size_t)row * T + t) * kFeat) + 4 * half;
       } else {
-        ar0[r] = make_rsrc(P.in0.ubase(row0 + r * 32, t), 0xffffffffu);
-        av0[r] = P.in0.voff(row0 + r * 32, t, l31, half) * 4;
+        const int rb = (args.dbg & 1) ? 0 : row0 + r * 32;
+        ar0[r] = make_rsrc(P.in0.ubase(rb, t), 0xffffffffu);
+        av0[r] = P.in0.voff(rb, t, l31, half) * 4;
         if constexpr (KQ1 > 0) {
-          ar1[r] = make_rsrc(P.in1.ubase(row0 + r * 32, t), 0xffffffffu);
-          av1[r] = P.in1.voff(row0 + r * 32, t, l31, half) * 4;
+          ar1[r] = make_rsrc(P.in1.ubase(rb, t), 0xffffffffu);
+          av1[r] = P.in1.voff(rb, t, l31, half) * 4;
         }
       }
     }
@@ -324,7 +361,10 @@ lstm_layer_kernel(const LstmArgs args) {
     }
 
     // ---- acc += h_{t-1} U   (h_0 = 0: nothing to add on the first step) -------------------------
+    // The previous step's h image (hcur) is also what still has to go out to HBM: its LDS reads are
+    // issued here, its BatchNorm + stores after the first k-group's MFMAs are in the pipe.
     if (s > 0) {
+      if (!(args.dbg & 2)) copyout_read(hcur);
       const float* hp = hcur + hr_off;
       f32x4 a[2][R], b[2][4];
 #pragma unroll
@@ -346,6 +386,7 @@ lstm_layer_kernel(const LstmArgs args) {
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[g][r] = mfma32(a[cur][r][j], b[cur][g][j], acc[g][r]);
+        if (kg == 0 && !(args.dbg & 2)) copyout_write(dir ? t + 1 : t - 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -359,7 +400,7 @@ lstm_layer_kernel(const LstmArgs args) {
       inproj(acc, preA, preB, [&](int slot) {
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-          if ((e * NSLOT) / NE == slot) gate(zv, hw, e / 16, e % 16);
+          if ((e * NSLOT) / NE == slot && !(args.dbg & 4)) gate(zv, hw, e / 16, e % 16);
       });
       loadB(WREC, brec0);                        // first recurrent weights of step s+1, ahead of the barrier
     } else {
@@ -368,24 +409,10 @@ lstm_layer_kernel(const LstmArgs args) {
     }
     __syncthreads();
 
-    // ---- h_t (+ fused BatchNorm) -> global, coalesced 16-byte stores --------------------------
-    {
-      constexpr int KQH = H / 4;                   // real chunks of this direction
-      constexpr int ITEMS = KQH * ROWS;            // float4 items
-      const int kq_total = 2 * KQH;
-      for (int it = threadIdx.x; it < ITEMS; it += NTHREADS) {
-        int kq = it / ROWS, rr = it % ROWS;
-        f32x4 v = *(const f32x4*)(hnxt + kq * PLANE + rr * 4);
-        const f32x4 sc = *(const f32x4*)(P.bn_scale + dir * H + kq * 4);
-        const f32x4 sh = *(const f32x4*)(P.bn_shift + dir * H + kq * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
-        int tile = blockIdx.x * (R * WR) + rr / 32;
-        float* dst = P.out + ((size_t)(tile * T + t) * kq_total + dir * KQH + kq) * 128 + (rr & 31) * 4;
-        *(f32x4*)dst = v;
-      }
-    }
   }
+  // last step's h
+  copyout_read(hbuf + (T & 1) * HBUF);
+  copyout_write(dir ? 0 : T - 1);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -410,12 +437,22 @@ struct CnnArgs {
 
 constexpr int kCnnThreads = 320;   // 32 events x 10 chunks of 5 positions; waves 0-3 also run the MFMAs
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
-  constexpr int XS = 56;                    // staged signal row stride (floats): [2 zero | 50 | 4 zero]
-  constexpr int PLANE = 32 * 4 + 4;         // floats per kq plane of the flat image
-  __shared__ __attribute__((aligned(16))) float xs[32 * XS];
-  __shared__ __attribute__((aligned(16))) float flat[100 * PLANE];
-  __shared__ __attribute__((aligned(16))) float red[2 * 32 * 33];
+  // One LDS region, reused phase by phase (52.8 KB -> three workgroups per CU):
+  //   [stage]  xs   32 x XS floats            staged signal rows, zero padded
+  //   [conv ]  flat 100 planes x PLANE floats  A-fragment image of the 400-vector (written after every
+  //                                            thread has its 9 samples in registers, so it may overlap xs)
+  //   [mfma ]  red  2 x 32 x 33                K-half partial sums, placed behind the planes the second
+  //                                            K-half has finished reading ... kept separate at the tail
+  constexpr int XS = 57;                    // odd stride: lanes r=0..31 hit 32 different banks
+  constexpr int PLANE = 32 * 4 + 4;         // floats per kq plane of the flat image (+4: conflict-free)
+  constexpr int RED = 2 * 32 * 33;
+  __shared__ __attribute__((aligned(16))) float lds[100 * PLANE];
+  float* xs = lds;
+  float* flat = lds;
+  float* red = lds;                         // reused only after the MFMA phase's barrier
 
   const CnnModelParams& P = args.m[blockIdx.y];
   const int T = args.T;
@@ -437,7 +474,11 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
   {
     const float* cw = P.conv;
     const int r = tid & 31, p0 = (tid >> 5) * 5;
-    const float* x = xs + r * XS + 2 + p0;        // x[-2..6] readable
+    float x[9];                                    // samples p0-2 .. p0+6
+#pragma unroll
+    for (int i = 0; i < 9; ++i) x[i] = xs[r * XS + p0 + i];
+    __syncthreads();                               // xs is dead: the image may overwrite it
+
     float b1v[7][8];                               // bn1 at positions p0-1 .. p0+5
     {
       float w1[48];                                // w1[3][8], b1[8], bn1 scale[8], shift[8]
@@ -447,7 +488,7 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
       for (int q = 0; q < 7; ++q) {
         int p = p0 - 1 + q;
         bool inside = (p >= 0) && (p < kSig);
-        float xm = x[q - 2], xc = x[q - 1], xp = x[q];
+        float xm = x[q], xc = x[q + 1], xp = x[q + 2];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
           float v = w1[24 + o];
@@ -460,26 +501,28 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
         }
       }
     }
-    // conv2, weight-stationary: each (tap k, in-channel ci) row of 8 weights is fetched once
-    // (one scalar dwordx8 load) and applied to all 5 positions of this thread: 40 FMAs per fetch.
+    // conv2, weight-stationary: each (tap k, in-channel ci) row of 8 weights is fetched once (one
+    // scalar dwordx8 load) and applied to all 5 positions of this thread as 4 packed FMAs each.
     const float* w2 = cw + 48;
-    float o5[5][8];
+    f32x2 o5[5][4];
 #pragma unroll
     for (int q = 0; q < 5; ++q)
 #pragma unroll
-      for (int o = 0; o < 8; ++o) o5[q][o] = w2[192 + o];
+      for (int o = 0; o < 4; ++o) o5[q][o] = f32x2{w2[192 + 2 * o], w2[192 + 2 * o + 1]};
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int ci = 0; ci < 8; ++ci) {
-        float wrow[8];
+        f32x2 wrow[4];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) wrow[o] = w2[(k * 8 + ci) * 8 + o];
+        for (int o = 0; o < 4; ++o)
+          wrow[o] = f32x2{w2[(k * 8 + ci) * 8 + 2 * o], w2[(k * 8 + ci) * 8 + 2 * o + 1]};
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-          float a = b1v[q + k][ci];
+          const float av = b1v[q + k][ci];
+          const f32x2 a2 = f32x2{av, av};
 #pragma unroll
-          for (int o = 0; o < 8; ++o) o5[q][o] = __builtin_fmaf(a, wrow[o], o5[q][o]);
+          for (int o = 0; o < 4; ++o) o5[q][o] = __builtin_elementwise_fma(a2, wrow[o], o5[q][o]);
         }
       }
     float s2[8], h2[8];
@@ -487,11 +530,11 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
     for (int o = 0; o < 8; ++o) { s2[o] = w2[200 + o]; h2[o] = w2[208 + o]; }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      float xc = x[q];
+      const float xc = x[q + 2];
       float o8[8];
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
-        float v = __builtin_fmaxf(o5[q][o], 0.f);
+        float v = __builtin_fmaxf(o5[q][o >> 1][o & 1], 0.f);
         v = v * s2[o] + h2[o];
         o8[o] = v + xc;                            // Add(): broadcast the raw signal over channels
       }
@@ -516,12 +559,15 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = mfma32(a[j], bq[j], acc);
     }
-    if (kh == 1) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) red[(nt * 32 + acc_row(reg, lane)) * 33 + l31] = acc[reg];
-    }
   }
-  __syncthreads();            // all reads of `flat` are done; reuse it as the output image
+  __syncthreads();            // all reads of the image are done; the region is free again
+  if (wave >= 2 && wave < 4) {
+    const int nt = wave & 1;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[(nt * 32 + acc_row(reg, lane)) * 33 + l31] = acc[reg];
+  }
+  __syncthreads();
+  float* outimg = lds + RED + 32;            // 16 planes behind the partial sums
   if (wave < 2) {
     const int nt = wave;
     const float bias = P.dbias[nt * 32 + l31];
@@ -530,13 +576,13 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
     for (int reg = 0; reg < 16; ++reg) {
       int row = acc_row(reg, lane);
       float v = (acc[reg] + red[(nt * 32 + row) * 33 + l31]) + bias;
-      flat[(u >> 2) * PLANE + row * 4 + (u & 3)] = v;
+      outimg[(u >> 2) * PLANE + row * 4 + (u & 3)] = v;
     }
   }
   __syncthreads();
   for (int it = tid; it < 16 * 32; it += kCnnThreads) {
     int kq = it >> 5, rr = it & 31;
-    f32x4 v = *(const f32x4*)(flat + kq * PLANE + rr * 4);
+    f32x4 v = *(const f32x4*)(outimg + kq * PLANE + rr * 4);
     *(f32x4*)(P.out + ((size_t)b * 16 + kq) * 128 + rr * 4) = v;
   }
 }

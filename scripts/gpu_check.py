@@ -47,8 +47,10 @@ for T in (13,):
     ds = torch.from_numpy(sig).cuda(); dr = torch.from_numpy(rd_).cuda()
     p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
     a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
-    for cfg in ("2,2,0,2", "2,2,1,2", "3,2,0,2", "2,2,0,0", "2,2,1,4"):
+    for cfg, dbg in (("2,2,0,2", 0), ("2,2,0,2", 0), ("2,2,0,2", 1), ("2,2,0,2", 2), ("2,2,0,2", 4), ("2,2,0,2", 7)):
         os.environ["NRV_GEO"] = cfg
+        os.environ["NRV_DBG"] = str(dbg)
+        print("DBG", dbg)
         rv2 = Reviser(a, b)
         for it in range(3):
             rv2.predict_device(ds.data_ptr(), dr.data_ptr(), 4096, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
