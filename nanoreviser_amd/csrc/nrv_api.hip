@@ -133,10 +133,11 @@ struct DevModel {
 struct nrv_handle {
   int device = 0, T = 0, act = 0, batch = 4096;
   hipStream_t own_stream = nullptr, stream = nullptr;
+
   DevModel dm[2];
   // workspace (per model)
   int cap_rows = 0;                // padded rows the workspace holds
-  float *S[2] = {0, 0}, *X1[2] = {0, 0}, *X2[2] = {0, 0}, *X3[2] = {0, 0};
+  float *S[2] = {0, 0}, *X1[2] = {0, 0}, *X2[2] = {0, 0}, *X3[2] = {0, 0}, *MO[2] = {0, 0};
   // staging for the host-pointer entry points
   float *d_sig = nullptr, *d_feat = nullptr, *d_p[2] = {0, 0};
   int8_t* d_a[2] = {0, 0};
@@ -224,6 +225,7 @@ static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
 static void free_workspace(nrv_handle* h) {
   for (int m = 0; m < 2; ++m) {
     (void)hipFree(h->S[m]); (void)hipFree(h->X1[m]); (void)hipFree(h->X2[m]); (void)hipFree(h->X3[m]);
+    (void)hipFree(h->MO[m]); h->MO[m] = nullptr;
     (void)hipFree(h->d_p[m]); (void)hipFree(h->d_a[m]);
     h->S[m] = h->X1[m] = h->X2[m] = h->X3[m] = h->d_p[m] = nullptr;
     h->d_a[m] = nullptr;
@@ -247,6 +249,8 @@ static int ensure_workspace(nrv_handle* h) {
     HIPCHK(h, hipMalloc(&h->X1[m], n1 * 4));
     HIPCHK(h, hipMalloc(&h->X2[m], n2 * 4));
     HIPCHK(h, hipMalloc(&h->X3[m], n3 * 4));
+    HIPCHK(h, hipMalloc(&h->MO[m], tiles * T * 256 * 4));
+    HIPCHK(h, hipMemset(h->MO[m], 0, tiles * T * 256 * 4));
     HIPCHK(h, hipMemset(h->S[m], 0, nS * 4));
     HIPCHK(h, hipMemset(h->X1[m], 0, n1 * 4));
     HIPCHK(h, hipMemset(h->X2[m], 0, n2 * 4));
@@ -312,7 +316,9 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   };
   int rc;
 
-  // 0: signal branch
+  // 0: signal branch.  (Running it on a second stream beside lstm1/lstm2 was measured: the
+  // dispatcher serialises the two launches anyway - each fills the LDS/register file of every CU -
+  // and the event fork/join costs ~20 us per group, so everything stays on one stream.)
   {
     CnnArgs a;
     for (int m = 0; m < 2; ++m) {
@@ -372,9 +378,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       const DevModel& d = h->dm[m];
       a.m[m] = HeadModelParams{d.all + d.d1p, d.all + d.d1b, d.all + d.d2p, d.all + d.d2b,
                                d.all + d.mop, d.all + d.mob, d.all + d.fw, d.all + d.fb,
-                               d.all + d.ow, d.all + d.ob, h->X2[m], dp[m], da[m], d.C};
+                               d.all + d.ow, d.all + d.ob, h->X2[m], h->MO[m], dp[m], da[m], d.C};
     }
-    hipLaunchKernelGGL(head_kernel, dim3(tiles, 2), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(head_mlp_kernel, dim3(tiles * T, 2), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(head_final_kernel, dim3(tiles, 2), dim3(128), 0, h->stream, a);
     if ((rc = mark(6))) return rc;
   }
   HIPCHK(h, hipGetLastError());
@@ -575,7 +582,7 @@ const char* nrv_kernel_name(int slot) {
   static const char* names[NRV_N_KERNELS] = {"cnn_kernel", "lstm_layer_kernel<lstm1 6->16>",
                                              "lstm_layer_kernel<lstm2 32->64>",
                                              "lstm_layer_kernel<lstm3 192->128>",
-                                             "lstm_layer_kernel<lstm4 256->64>", "head_kernel"};
+                                             "lstm_layer_kernel<lstm4 256->64>", "head_mlp_kernel+head_final_kernel"};
   return (slot >= 0 && slot < NRV_N_KERNELS) ? names[slot] : "";
 }
 

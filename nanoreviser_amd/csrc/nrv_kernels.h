@@ -207,26 +207,33 @@ lstm_layer_kernel(const LstmArgs args) {
   for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
   for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
     bnl[i] = i < H ? P.bn_scale[dir * H + i] : P.bn_shift[dir * H + i - H];
+  __syncthreads();
 
   // ---- h_t (+ fused BatchNorm) -> HBM: LDS image -> 16-byte coalesced stores.  Split in two so the
   // LDS reads are issued ahead of, and the stores behind, the first recurrent MFMAs of the next step.
   constexpr int KQH = H / 4;                   // real 4-feature chunks of this direction
-  constexpr int ITEMS = KQH * ROWS;            // float4 items per step
-  constexpr int NIT = (ITEMS + NTHREADS - 1) / NTHREADS;
+  // NG > 1: the whole workgroup copies the whole image.  NG == 1: every wave copies its own rows.
+  constexpr int CROWS = (NG > 1) ? ROWS : 32 * R;
+  constexpr int CTHREADS = (NG > 1) ? NTHREADS : 64;
+  constexpr int ITEMS = KQH * CROWS;           // float4 items per step
+  constexpr int NIT = (ITEMS + CTHREADS - 1) / CTHREADS;
+  const int ctid = (NG > 1) ? threadIdx.x : lane;
+  const int crow0 = (NG > 1) ? 0 : lrow0;
   f32x4 cov[NIT];
   auto copyout_read = [&](const float* himg) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int it = threadIdx.x + i * NTHREADS;
-      if (ITEMS % NTHREADS == 0 || it < ITEMS) cov[i] = *(const f32x4*)(himg + (it / ROWS) * PLANE + (it % ROWS) * 4);
+      const int it = ctid + i * CTHREADS;
+      if (ITEMS % CTHREADS == 0 || it < ITEMS)
+        cov[i] = *(const f32x4*)(himg + (it / CROWS) * PLANE + (crow0 + it % CROWS) * 4);
     }
   };
   auto copyout_write = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int it = threadIdx.x + i * NTHREADS;
-      if (ITEMS % NTHREADS == 0 || it < ITEMS) {
-        const int kq = it / ROWS, rr = it % ROWS;
+      const int it = ctid + i * CTHREADS;
+      if (ITEMS % CTHREADS == 0 || it < ITEMS) {
+        const int kq = it / CROWS, rr = crow0 + it % CROWS;
         const f32x4 sc = *(const f32x4*)(bnl + kq * 4);
         const f32x4 sh = *(const f32x4*)(bnl + H + kq * 4);
         f32x4 v = cov[i];
@@ -407,7 +414,10 @@ lstm_layer_kernel(const LstmArgs args) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) gate(zv, hw, e / 16, e % 16);
     }
-    __syncthreads();
+    // h_t must be visible to the other hidden groups of this row block before the next recurrent
+    // product.  With a single hidden group (NG == 1) the wave only ever reads its own rows (the
+    // copy-out is per wave too), and DS operations of one wave complete in order: no barrier.
+    if constexpr (NG > 1) __syncthreads();
 
   }
   // last step's h
@@ -606,6 +616,7 @@ struct HeadModelParams {
   const float* outw;      // [16][C]
   const float* outb;      // [C]
   const float* in;        // LSTM4 output, tiled window-major KQ=32
+  float* mo;              // main_out scratch [tile][t][32 rows][8]  (6 used)
   float* prob;            // [n][C]
   int8_t* argmax;         // [n]
   int n_class;
@@ -618,94 +629,120 @@ struct HeadArgs {
 
 constexpr int kHeadMaxT = 32;
 
-__global__ void __launch_bounds__(256) head_kernel(const HeadArgs args) {
+// Stage 1: one WAVE per (row tile, timestep, model): three chained per-timestep layers on MFMA,
+// intermediate activations through a wave-private LDS image (no workgroup barrier at all), weights
+// streamed in B-fragment order with a two-group register ring.  grid = (tiles*T, 2), block = 64.
+__global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
   constexpr int PLANE = 32 * 4 + 4;
-  __shared__ __attribute__((aligned(16))) float img[4][32 * PLANE];   // per-wave A image, up to 128 features
-  __shared__ float flatv[32 * (6 * kHeadMaxT + 1)];
-  __shared__ float featv[32 * 17];
-  __shared__ float logit[32 * 8];
-
+  __shared__ __attribute__((aligned(16))) float im[32 * PLANE];      // up to 128 features
   const HeadModelParams& P = args.m[blockIdx.y];
-  const int T = args.T;
-  const int tile = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const int FS = 6 * T + 1;
-  float* im = img[wave];
+  const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+  const int bt = blockIdx.x;                                          // tile*T + t
 
-  for (int t = wave; t < T; t += 4) {
-    // dense1: 128 -> 128, A from global
-    f32x16 acc[4];
+  // dense1: 128 -> 128, A straight from the tiled LSTM4 output
+  f32x16 acc[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = splat16(P.d1bias[nt * 32 + l31]);
-    const float* ap = P.in + ((size_t)(tile * T + t) * 32 + half) * 128 + l31 * 4;
-    const float* wp = P.d1pack + lane * 4;
-#pragma unroll 2
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = splat16(P.d1bias[nt * 32 + l31]);
+  {
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(P.in + (size_t)bt * 32 * 128, 32 * 128 * 4);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.d1pack, 4 * 16 * 256 * 4);
+    const unsigned av = (half * 128 + l31 * 4) * 4, wv = lane * 16;
+    f32x4 a[3], b[3][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i] = buf_load16(ars, av, i * 1024);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) b[i][nt] = buf_load16(wrs, wv, (nt * 16 + i) * 1024);
+    }
+#pragma unroll
     for (int kg = 0; kg < 16; ++kg) {
-      f32x4 a = *(const f32x4*)(ap + kg * 256);
-      f32x4 b[4];
+      if (kg + 2 < 16) {
+        a[(kg + 2) % 3] = buf_load16(ars, av, (kg + 2) * 1024);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) b[nt] = *(const f32x4*)(wp + (nt * 16 + kg) * 256);
+        for (int nt = 0; nt < 4; ++nt) b[(kg + 2) % 3][nt] = buf_load16(wrs, wv, (nt * 16 + kg + 2) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma32(a[j], b[nt][j], acc[nt]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      int u = nt * 32 + l31;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        im[(u >> 2) * PLANE + acc_row(reg, lane) * 4 + (u & 3)] = __builtin_fmaxf(acc[nt][reg], 0.f);
-    }
-    // dense2: 128 -> 32 (same wave wrote the image; LDS ops of one wave complete in order)
-    f32x16 a2 = splat16(P.d2bias[l31]);
-    {
-      const float* hp = im + half * PLANE + l31 * 4;
-      const float* w2 = P.d2pack + lane * 4;
-#pragma unroll 4
-      for (int kg = 0; kg < 16; ++kg) {
-        f32x4 a = *(const f32x4*)(hp + kg * 2 * PLANE);
-        f32x4 b = *(const f32x4*)(w2 + kg * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a2 = mfma32(a[j], b[j], a2);
-      }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-      im[(l31 >> 2) * PLANE + acc_row(reg, lane) * 4 + (l31 & 3)] = __builtin_fmaxf(a2[reg], 0.f);
-    // main_out: 32 -> 6 (padded to 32 columns)
-    f32x16 a3 = splat16(P.mobias[l31]);
-    {
-      const float* hp = im + half * PLANE + l31 * 4;
-      const float* w3 = P.mopack + lane * 4;
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        f32x4 a = *(const f32x4*)(hp + kg * 2 * PLANE);
-        f32x4 b = *(const f32x4*)(w3 + kg * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a3 = mfma32(a[j], b[j], a3);
-      }
-    }
-    if (l31 < 6) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        flatv[acc_row(reg, lane) * FS + t * 6 + l31] = __builtin_fmaxf(a3[reg], 0.f);
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma32(a[kg % 3][j], b[kg % 3][nt][j], acc[nt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
+  // first weights of the next two layers, requested before the LDS round trip
+  f32x4 w2[16], w3[4];
+#pragma unroll
+  for (int kg = 0; kg < 16; ++kg) w2[kg] = *(const f32x4*)(P.d2pack + kg * 256 + lane * 4);
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) w3[kg] = *(const f32x4*)(P.mopack + kg * 256 + lane * 4);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int u = nt * 32 + l31;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      im[(u >> 2) * PLANE + acc_row(reg, lane) * 4 + (u & 3)] = __builtin_fmaxf(acc[nt][reg], 0.f);
+  }
+  // dense2: 128 -> 32 (the same wave wrote the image; DS operations of one wave complete in order)
+  f32x16 a2 = splat16(P.d2bias[l31]);
+  {
+    const float* hp = im + half * PLANE + l31 * 4;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) {
+      const f32x4 a = *(const f32x4*)(hp + kg * 2 * PLANE);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a2 = mfma32(a[j], w2[kg][j], a2);
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg)
+    im[(l31 >> 2) * PLANE + acc_row(reg, lane) * 4 + (l31 & 3)] = __builtin_fmaxf(a2[reg], 0.f);
+  // main_out: 32 -> 6 (padded to 32 columns)
+  f32x16 a3 = splat16(P.mobias[l31]);
+  {
+    const float* hp = im + half * PLANE + l31 * 4;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const f32x4 a = *(const f32x4*)(hp + kg * 2 * PLANE);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a3 = mfma32(a[j], w3[kg][j], a3);
+    }
+  }
+  if (l31 < 8) {
+    float* dst = P.mo + (size_t)bt * 32 * 8 + l31;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) dst[acc_row(reg, lane) * 8] = __builtin_fmaxf(a3[reg], 0.f);
+  }
+}
 
-  // feature: (6T) -> 16, relu
-  for (int it = tid; it < 32 * 16; it += 256) {
-    int r = it >> 4, f = it & 15;
+// Stage 2: Flatten(6T) -> Dense(16,relu) -> Dense(C,softmax) -> argmax, one row tile per workgroup.
+// 96T+96 MAC per window: VALU.  grid = (tiles, 2), block = 128.
+__global__ void __launch_bounds__(128) head_final_kernel(const HeadArgs args) {
+  __shared__ float flatv[32 * (6 * kHeadMaxT + 1)];
+  __shared__ float featw[6 * kHeadMaxT * 16];
+  __shared__ float featv[32 * 17];
+  __shared__ float logit[32 * 8];
+  const HeadModelParams& P = args.m[blockIdx.y];
+  const int T = args.T, tile = blockIdx.x, tid = threadIdx.x;
+  const int FS = 6 * T + 1;
+  for (int i = tid; i < 6 * T * 16; i += 128) featw[i] = P.featw[i];
+  for (int i = tid; i < T * 32 * 8; i += 128) {                    // coalesced read of [t][row][8]
+    const int k = i & 7, r = (i >> 3) & 31, t = i >> 8;
+    const float v = P.mo[(size_t)(tile * T) * 256 + i];
+    if (k < 6) flatv[r * FS + t * 6 + k] = v;
+  }
+  __syncthreads();
+  for (int it = tid; it < 32 * 16; it += 128) {
+    const int r = it >> 4, f = it & 15;
     float v = P.featb[f];
     const float* fr = flatv + r * FS;
-    for (int k = 0; k < 6 * T; ++k) v = __builtin_fmaf(fr[k], P.featw[k * 16 + f], v);
+#pragma unroll 6
+    for (int k = 0; k < 6 * T; ++k) v = __builtin_fmaf(fr[k], featw[k * 16 + f], v);
     featv[r * 17 + f] = __builtin_fmaxf(v, 0.f);
   }
   __syncthreads();
   const int C = P.n_class;
-  if (tid < 32 * 8) {
-    int r = tid >> 3, cc = tid & 7;
+  for (int it = tid; it < 32 * 8; it += 128) {
+    const int r = it >> 3, cc = it & 7;
     if (cc < C) {
       float v = P.outb[cc];
 #pragma unroll
@@ -715,7 +752,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadArgs args) {
   }
   __syncthreads();
   if (tid < 32) {
-    int row = tile * 32 + tid;
+    const int row = tile * 32 + tid;
     if (row < args.n_rows) {
       float mx = logit[tid * 8];
       for (int cc = 1; cc < C; ++cc) mx = __builtin_fmaxf(mx, logit[tid * 8 + cc]);
@@ -723,7 +760,7 @@ __global__ void __launch_bounds__(256) head_kernel(const HeadArgs args) {
       for (int cc = 0; cc < C; ++cc) { e[cc] = expf(logit[tid * 8 + cc] - mx); sum += e[cc]; }
       int best = 0; float bv = -1.f;
       for (int cc = 0; cc < C; ++cc) {
-        float p = e[cc] / sum;
+        const float p = e[cc] / sum;
         P.prob[(size_t)row * C + cc] = p;
         if (p > bv) { bv = p; best = cc; }     // strict > : ties -> lowest index
       }
