@@ -1,0 +1,284 @@
+"""Command line of the MI355X reviser: the reference's `NanoReviser.py` contract, fast5 in,
+`<read>_out.fasta` / `_out.fastq` out.
+
+Kept from the reference (NanoReviser.py:42-95, 105-236):
+  * the flag surface  -d -o -F -S --thread -t -e -g -s --test_mode --model1_predict_dir
+    --model2_predict_dir -v ;
+  * weight path convention ./model/<S>/<S>_win13_50ep_model{1,2}.h5 (:191-193);
+  * one output file per read, `<output_dir><stem>_out.<fmt>` with stem = name up to the first '.'
+    (:137, :163) and the record layout of output_handeler.py:26-62;
+  * the failure contract: any error while revising a read writes the ORIGINAL basecalls instead
+    (:146-152 fasta, :173-179 fastq via extract_fastq) - and, which the reference parses but never
+    does (:63-65), the read is listed in the --failed_read file.
+Changed on purpose:
+  * the network is actually executed (the reference shells out to a missing Guppy binary,
+    SURVEY.md F1): per read  events -> bases -> signal windows/features (hoststage) ->
+    nrv_predict_read on the GPU -> merge (hoststage.revise_read);
+  * no tmp-dir copies (the -t flag is accepted and ignored; the reference's per-slot tmp dirs race,
+    :111) and no file is dropped when the count is not a multiple of the pool size (:212);
+  * reads are sharded over the visible GPUs, one worker process per GPU, no collectives
+    (--gpus, default all); --thread bounds the host-side parsing threads per worker;
+  * explicitly given --model{1,2}_predict_dir win over -S (in the reference -S always overrides
+    them, which makes those flags dead, :191-193).
+FASTQ qualities: the reviser has no Guppy qualities; each revised base gets
+Phred = -10 log10(1 - min(p_model1, p_model2)) of its call (capped 1..40), unrevised edge bases '#'.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import h5lite
+from . import hoststage as hs
+from .shard import shard_reads
+from .weights import load_model
+
+VERSION = "1.0"
+
+
+def get_args(argv: Optional[Sequence[str]] = None):
+    p = argparse.ArgumentParser(
+        prog="NanoReviser.py", usage="%(prog)s [-d] [-o]",
+        description="An Error-correction Tool for Nanopore Sequencing Based on a Deep Learning Algorithm "
+                    "(MI355X engine)")
+    p.add_argument("-d", "--fast5_base_dir", dest="fast5_base_dir", help="path to the fast5 files")
+    p.add_argument("-o", "--output_dir", dest="output_dir", default="./unitest/nanorev_output/",
+                   help="path to store the output files")
+    p.add_argument("-F", "--output_format", dest="output_format", default="fasta",
+                   help="format of the output files, default is fasta")
+    p.add_argument("-S", "--species", dest="species", default="human", help="ecoli or human")
+    p.add_argument("--thread", dest="thread", type=int, default=100,
+                   help="host parsing threads per GPU worker (capped at the core count)")
+    p.add_argument("-t", "--tmp_dir", dest="temp_dir", default="./unitest/tmp/", help="accepted, unused")
+    p.add_argument("-e", "--failed_read", dest="failed_reads_filename", default="failed_reads.txt",
+                   help="document to log the failed reads")
+    p.add_argument("-g", "--basecall_group", dest="basecall_group", default="Basecall_1D_000")
+    p.add_argument("-s", "--basecall_subgroup", dest="basecall_subgroup", default="BaseCalled_template")
+    p.add_argument("--test_mode", action="store_true", default=False, help="just for unitest")
+    p.add_argument("--model1_predict_dir", dest="model1_predict_dir", default=None)
+    p.add_argument("--model2_predict_dir", dest="model2_predict_dir", default=None)
+    p.add_argument("-v", "--virsion", action="store_true", dest="virsion", help="version of NanoReviser")
+    p.add_argument("--gpus", type=int, default=0, help="GPUs to use (0 = all visible)")
+    p.add_argument("--batch", type=int, default=4096, help="windows per device launch group")
+    p.add_argument("--model_dir", default=None, help="root of model/<species>/ (default: next to the package)")
+    a = p.parse_args(argv)
+    if a.virsion:
+        print(f"The virsion of NanoReviser : {VERSION} ")
+        raise SystemExit(0)
+    if not (a.fast5_base_dir and a.output_dir):
+        p.print_help()
+        raise SystemExit(0)
+    return a
+
+
+def model_paths(args):
+    """NanoReviser.py:188-194."""
+    root = args.model_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "model")
+    sp = "ecoli" if (args.test_mode and not args.species) else args.species
+    p1 = args.model1_predict_dir or os.path.join(root, sp, f"{sp}_win13_50ep_model1.h5")
+    p2 = args.model2_predict_dir or os.path.join(root, sp, f"{sp}_win13_50ep_model2.h5")
+    ok = all(os.path.exists(p) or os.path.exists(os.path.splitext(p)[0] + ".f32") for p in (p1, p2))
+    if not ok:
+        raise RuntimeError("！！！[Error] model file: Please check the dir of models file!!")
+    return p1, p2
+
+
+def out_name(output_dir: str, fast5_fn: str, fmt: str) -> str:
+    # NanoReviser.py:137/163: plain string concatenation with output_dir, stem = up to the first '.'
+    return output_dir + fast5_fn.split(".")[0] + "_out." + fmt
+
+
+def parse_read(path: str, group: str, subgroup: str):
+    """fast5 -> (ReadData, fastq text or None).  nanorev_fast5_handeler.py:58-150."""
+    d = h5lite.read_fast5(path, group, subgroup)
+    ev = d["events"]
+    start, length = ev["start"], ev["length"]
+    try:
+        old = tuple(int(x) for x in d["version"].split(".")[:2]) <= (0, 0)
+    except ValueError:
+        old = False
+    if old:                                   # pre-versioned Albacore: times in seconds (:66-71)
+        start = start * 4000 - d["raw_attrs"]["start_time"]
+        length = length * 4000
+    rd = hs.collapse_events(start, ev["mean"], ev["stdv"], ev["model_state"], ev["move"], d["signal"])
+    fq = d["fastq"].decode("utf8") if d["fastq"] is not None else None
+    return rd, fq
+
+
+def phred_chars(p1: np.ndarray, p2: np.ndarray) -> np.ndarray:
+    conf = np.minimum(p1.max(-1), p2.max(-1)).astype(np.float64)
+    q = np.clip(np.round(-10.0 * np.log10(np.maximum(1.0 - conf, 1e-4))), 1, 40).astype(np.int64)
+    return (q + 33).astype(np.uint8)
+
+
+def revise_one(reviser, rd: hs.ReadData):
+    """One read through the engine -> (revised sequence, per-base quality string)."""
+    rt = hs.read_tensors(rd)
+    p1, p2, a1, a2 = reviser.predict_read(rt.sig_ev, rt.feat_ev)
+    T = reviser.T
+    seq = hs.revise_read(rd.bases, a1, a2, T)
+    # qualities follow the same merge walk
+    off, n = (T - 1) // 2, len(a1)
+    qc = phred_chars(p1, p2) if n else np.zeros(0, np.uint8)
+    qual: List[int] = [ord("#")] * min(off, len(rd.bases))
+    l1 = np.asarray(a1).astype(np.int64)
+    l2 = np.asarray(a2).astype(np.int64) + 1
+    for i in range(n):
+        x, y = hs.LABEL_TO_BASE[int(l1[i])], hs.LABEL_TO_BASE[int(l2[i])]
+        if x == "D" and y in hs._ACGT:
+            qual.extend((int(qc[i]), int(qc[i])))
+        elif x == "-" and y == "-":
+            continue
+        else:
+            qual.append(int(qc[i]))
+    qual.extend([ord("#")] * (len(seq) - len(qual)))
+    return seq, bytes(qual[:len(seq)]).decode("ascii")
+
+
+def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
+    os.makedirs(args.output_dir, exist_ok=True)
+    if args.output_format == "fastq":
+        text = hs.fastq_record(fast5_fn, list(seq), list(qual if qual is not None else "#" * len(seq)))
+    else:
+        text = hs.fasta_record(fast5_fn, list(seq))
+    with open(out_name(args.output_dir, fast5_fn, args.output_format), "w") as fp:
+        fp.write(text)
+
+
+def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None]) -> dict:
+    """Revise `files` (names inside args.fast5_base_dir) with one engine.  Returns counters."""
+    stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
+    nthreads = max(1, min(int(args.thread), os.cpu_count() or 1, 32))
+
+    def load(fn):
+        t0 = time.perf_counter()
+        try:
+            return fn, parse_read(os.path.join(args.fast5_base_dir, fn), args.basecall_group,
+                                  args.basecall_subgroup), None, time.perf_counter() - t0
+        except Exception as e:                       # broken file: nothing to fall back to
+            return fn, None, e, time.perf_counter() - t0
+
+    def bounded_map(pool, fn, items, depth):
+        """pool.map with at most `depth` parsed reads in flight (a read is ~1 MB of arrays)."""
+        from collections import deque
+        pend, it = deque(), iter(items)
+        for x in it:
+            pend.append(pool.submit(fn, x))
+            if len(pend) >= depth:
+                yield pend.popleft().result()
+        while pend:
+            yield pend.popleft().result()
+
+    with ThreadPoolExecutor(nthreads) as pool:
+        for fn, parsed, err, dt in bounded_map(pool, load, files, 4 * nthreads):
+            stats["host_s"] += dt
+            if parsed is None:
+                log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {err}")
+                stats["failed"].append(fn)
+                continue
+            rd, fq = parsed
+            try:
+                t0 = time.perf_counter()
+                seq, qual = revise_one(reviser, rd)
+                stats["engine_s"] += time.perf_counter() - t0
+                write_read(args, fn, seq, qual)
+                stats["bases"] += len(seq)
+                if not args.test_mode:
+                    log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved......")
+                else:
+                    log("INFO Congratulations, NanoReviser is installed properly")
+            except Exception as e:                   # NanoReviser.py:146-152 / :173-179
+                stats["failed"].append(fn)
+                log(f"[！！！Error] revising {fn.split('.')[0]}: {e}; writing the original basecalls")
+                try:
+                    if args.output_format == "fastq" and fq is not None:
+                        b, q = hs.trim_fastq(fq)
+                        write_read(args, fn, b, q)
+                    else:
+                        orig = "".join(x.decode() for x in rd.bases.tolist())
+                        write_read(args, fn, orig, None)
+                except Exception as e2:
+                    log(f"[！！！Error] stroring : {fn.split('.')[0]}_out.{args.output_format}...... {e2}")
+            stats["reads"] += 1
+    return stats
+
+
+def _default_factory(args, device: int):
+    from .engine import Reviser
+    p1, p2 = model_paths(args)
+    return Reviser(load_model(p1), load_model(p2), device=device, batch=args.batch)
+
+
+def _worker(rank: int, world: int, args, files: List[str], q):
+    try:
+        rv = _default_factory(args, rank)
+        st = process_files(args, files, rv, print)
+        rv.close()
+        q.put((rank, st, None))
+    except BaseException as e:           # engine could not be created: loud, no silent fallback
+        q.put((rank, None, repr(e)))
+
+
+def main(argv: Optional[Sequence[str]] = None, reviser_factory=None) -> int:
+    args = get_args(argv)
+    if args.output_format not in ("fasta", "fastq"):
+        print("[！！！Error] output_format must be fasta or fastq", file=sys.stderr)
+        return 2
+    model_paths(args)                     # existence check up front (NanoReviser.py:194)
+    names = sorted(f for f in os.listdir(args.fast5_base_dir) if f.endswith(".fast5"))
+    os.makedirs(args.output_dir, exist_ok=True)
+    t0 = time.time()
+    if reviser_factory is not None:       # in-process (tests / embedding): one engine, no sharding
+        rv = reviser_factory(args, 0)
+        stats = [process_files(args, names, rv, print)]
+    else:
+        import torch
+        import torch.multiprocessing as mp
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            print("[！！！Error] no MI355X / HIP device visible: the reviser has no CPU path", file=sys.stderr)
+            return 2
+        world = min(args.gpus or ndev, ndev, max(1, len(names)))
+        sizes = [os.path.getsize(os.path.join(args.fast5_base_dir, f)) for f in names]
+        parts = shard_reads(sizes, world)
+        if world == 1:
+            rv = _default_factory(args, 0)
+            stats = [process_files(args, names, rv, print)]
+            rv.close()
+        else:
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_worker, args=(r, world, args, [names[i] for i in parts[r]], q))
+                     for r in range(world)]
+            for pr in procs:
+                pr.start()
+            res = [q.get() for _ in procs]
+            for pr in procs:
+                pr.join()
+            bad = [e for _, s, e in res if s is None]
+            if bad:
+                print(f"[！！！Error] worker failed: {bad[0]}", file=sys.stderr)
+                return 2
+            stats = [s for _, s, _ in res]
+    failed = [f for s in stats for f in s["failed"]]
+    with open(os.path.join(args.output_dir, args.failed_reads_filename), "w") as fp:
+        fp.write("".join(f + "\n" for f in failed))
+    dt = time.time() - t0
+    if not args.test_mode:
+        nb = sum(s["bases"] for s in stats)
+        print("[s:::] All subprocesses done.")
+        print("[s:::] NanoReviser time consuming:%.2f seconds" % dt)
+        print(f"[s:::] {sum(s['reads'] for s in stats)} reads, {nb} bases, {len(failed)} failed, "
+              f"{nb / max(dt, 1e-9):.0f} bases/s end to end")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

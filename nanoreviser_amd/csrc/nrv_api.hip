@@ -381,7 +381,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                d.all + d.ow, d.all + d.ob, h->X2[m], h->MO[m], dp[m], da[m], d.C};
     }
     hipLaunchKernelGGL(head_mlp_kernel, dim3(tiles * T, 2), dim3(64), 0, h->stream, a);
-    hipLaunchKernelGGL(head_final_kernel, dim3(tiles, 2), dim3(128), 0, h->stream, a);
+    hipLaunchKernelGGL(head_final_kernel, dim3(tiles, 2), dim3(256), 0, h->stream, a);
     if ((rc = mark(6))) return rc;
   }
   HIPCHK(h, hipGetLastError());

@@ -715,34 +715,47 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
 }
 
 // Stage 2: Flatten(6T) -> Dense(16,relu) -> Dense(C,softmax) -> argmax, one row tile per workgroup.
-// 96T+96 MAC per window: VALU.  grid = (tiles, 2), block = 128.
-__global__ void __launch_bounds__(128) head_final_kernel(const HeadArgs args) {
-  __shared__ float flatv[32 * (6 * kHeadMaxT + 1)];
-  __shared__ float featw[6 * kHeadMaxT * 16];
+// 96T+96 MAC per window: VALU, operands as 16-byte LDS reads.  grid = (tiles, 2), block = 256.
+__global__ void __launch_bounds__(256) head_final_kernel(const HeadArgs args) {
+  constexpr int KPMAX = 6 * kHeadMaxT;           // 192, multiple of 4
+  constexpr int FSM = KPMAX + 4;                 // row stride (floats): 16-byte aligned, bank-skewed
+  __shared__ __attribute__((aligned(16))) float flatv[32 * FSM];
+  __shared__ __attribute__((aligned(16))) float fwT[16 * FSM];    // feature kernel, transposed [f][k]
   __shared__ float featv[32 * 17];
   __shared__ float logit[32 * 8];
   const HeadModelParams& P = args.m[blockIdx.y];
   const int T = args.T, tile = blockIdx.x, tid = threadIdx.x;
-  const int FS = 6 * T + 1;
-  for (int i = tid; i < 6 * T * 16; i += 128) featw[i] = P.featw[i];
-  for (int i = tid; i < T * 32 * 8; i += 128) {                    // coalesced read of [t][row][8]
+  const int K = 6 * T, KP = (K + 3) & ~3;
+  for (int i = tid; i < 16 * KP; i += 256) {
+    const int f = i / KP, k = i % KP;
+    fwT[f * FSM + k] = k < K ? P.featw[k * 16 + f] : 0.f;
+  }
+  for (int i = tid; i < 32 * (KP - K); i += 256) flatv[(i / (KP - K)) * FSM + K + i % (KP - K)] = 0.f;
+  for (int i = tid; i < T * 32 * 8; i += 256) {                    // coalesced read of [t][row][8]
     const int k = i & 7, r = (i >> 3) & 31, t = i >> 8;
     const float v = P.mo[(size_t)(tile * T) * 256 + i];
-    if (k < 6) flatv[r * FS + t * 6 + k] = v;
+    if (k < 6) flatv[r * FSM + t * 6 + k] = v;
   }
   __syncthreads();
-  for (int it = tid; it < 32 * 16; it += 128) {
+  for (int it = tid; it < 32 * 16; it += 256) {
     const int r = it >> 4, f = it & 15;
     float v = P.featb[f];
-    const float* fr = flatv + r * FS;
-#pragma unroll 6
-    for (int k = 0; k < 6 * T; ++k) v = __builtin_fmaf(fr[k], featw[k * 16 + f], v);
+    const f32x4* fr = (const f32x4*)(flatv + r * FSM);
+    const f32x4* fw = (const f32x4*)(fwT + f * FSM);
+#pragma unroll 4
+    for (int k4 = 0; k4 < KP / 4; ++k4) {
+      const f32x4 x = fr[k4], w = fw[k4];
+      v = __builtin_fmaf(x[0], w[0], v);
+      v = __builtin_fmaf(x[1], w[1], v);
+      v = __builtin_fmaf(x[2], w[2], v);
+      v = __builtin_fmaf(x[3], w[3], v);
+    }
     featv[r * 17 + f] = __builtin_fmaxf(v, 0.f);
   }
   __syncthreads();
   const int C = P.n_class;
-  for (int it = tid; it < 32 * 8; it += 128) {
-    const int r = it >> 3, cc = it & 7;
+  {
+    const int r = tid >> 3, cc = tid & 7;
     if (cc < C) {
       float v = P.outb[cc];
 #pragma unroll

@@ -1,0 +1,148 @@
+"""The NanoReviser.py counterpart (nanoreviser_amd/cli.py): flag surface, file contract, failure
+contract.  CPU tests drive it with a stand-in engine object (host logic only, no compute); the
+GPU test runs the real thing end to end on two reference fixture reads."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_read
+from nanoreviser_amd import cli
+from nanoreviser_amd import hoststage as hs
+
+FAST5 = os.path.join(GOLD, "fast5")
+
+
+class EchoEngine:
+    """Stand-in for engine.Reviser in host-logic tests: 'predicts' exactly the original base at
+    every window centre (model1 label, model2 label-1), so revise_read must return the input."""
+    T = 11
+
+    def __init__(self, fail_on=None):
+        self.fail_on, self.calls = fail_on, 0
+
+    def predict_read(self, sig_ev, feat_ev):
+        self.calls += 1
+        if self.fail_on is not None and self.calls == self.fail_on:
+            raise RuntimeError("injected engine failure")
+        assert sig_ev.dtype == np.float32 and sig_ev.shape[1] == 50 and feat_ev.shape[1] == 6
+        n = len(feat_ev) - self.T
+        col = np.rint(feat_ev[:, 0] * 300).astype(int)                 # 250/180/100/30 -> A/G/T/C
+        lab = np.select([col == 250, col == 180, col == 100, col == 30], [5, 4, 3, 2])
+        a1 = lab[5:5 + n].astype(np.int8)
+        p1 = np.eye(6, dtype=np.float32)[a1] * 0.9 + 0.1 / 6
+        p2 = np.eye(5, dtype=np.float32)[a1 - 1] * 0.9 + 0.1 / 5
+        return p1, p2, a1, (a1 - 1).astype(np.int8)
+
+
+def test_flag_surface_matches_reference():
+    # NanoReviser.py:42-95
+    a = cli.get_args(["-d", "in/", "-o", "out/", "-F", "fastq", "-S", "ecoli", "--thread", "7", "-t", "tmp/",
+                      "-e", "bad.txt", "-g", "Basecall_1D_001", "-s", "BaseCalled_complement", "--test_mode",
+                      "--model1_predict_dir", "a.h5", "--model2_predict_dir", "b.h5"])
+    assert (a.fast5_base_dir, a.output_dir, a.output_format, a.species, a.thread) == ("in/", "out/", "fastq", "ecoli", 7)
+    assert (a.temp_dir, a.failed_reads_filename, a.basecall_group, a.basecall_subgroup) == \
+        ("tmp/", "bad.txt", "Basecall_1D_001", "BaseCalled_complement")
+    assert a.test_mode and a.model1_predict_dir == "a.h5" and a.model2_predict_dir == "b.h5"
+    d = cli.get_args(["-d", "x"])
+    assert (d.output_dir, d.output_format, d.species, d.thread, d.temp_dir, d.failed_reads_filename,
+            d.basecall_group, d.basecall_subgroup) == ("./unitest/nanorev_output/", "fasta", "human", 100,
+                                                       "./unitest/tmp/", "failed_reads.txt", "Basecall_1D_000",
+                                                       "BaseCalled_template")
+    with pytest.raises(SystemExit):
+        cli.get_args(["-v"])
+    with pytest.raises(SystemExit):
+        cli.get_args([])                        # -d missing -> help, exit (NanoReviser.py:93-95)
+    p1, p2 = cli.model_paths(cli.get_args(["-d", "x", "-S", "ecoli"]))
+    assert p1.endswith("model/ecoli/ecoli_win13_50ep_model1.h5") and p2.endswith("ecoli_win13_50ep_model2.h5")
+    with pytest.raises(RuntimeError):
+        cli.model_paths(cli.get_args(["-d", "x", "-S", "yeast"]))
+
+
+def test_parse_read_equals_reference_get_read_data():
+    for p in sorted(glob.glob(os.path.join(FAST5, "*.fast5"))):
+        key = "_".join(os.path.basename(p).split("_")[-3:-1])
+        g, rd_ref, _ = load_read(key)
+        rd, fq = cli.parse_read(p, "Basecall_1D_000", "BaseCalled_template")
+        assert rd.abs_event_start == int(g["rd_abs_event_start"])
+        assert np.array_equal(rd.start, g["rd_start"]) and np.array_equal(rd.bases, g["rd_bases"])
+        assert np.array_equal(rd.ab_mean, g["rd_ab_mean"]) and np.array_equal(rd.length, g["rd_length"])
+        assert hs.trim_fastq(fq) == (bytes(g["fq_bases"]).decode(), bytes(g["fq_qual"]).decode())
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+def test_file_contract_with_echo_engine(tmp_path, fmt):
+    out = str(tmp_path) + "/out/"
+    rc = cli.main(["-d", FAST5, "-o", out, "-F", fmt, "-S", "ecoli", "--thread", "2"],
+                  reviser_factory=lambda args, dev: EchoEngine())
+    assert rc == 0
+    files = sorted(os.listdir(FAST5))
+    for fn in files:
+        key = "_".join(fn.split("_")[-3:-1])
+        _, rd, _ = load_read(key)
+        orig = "".join(b.decode() for b in rd.bases.tolist())
+        path = out + fn.split(".")[0] + "_out." + fmt                  # NanoReviser.py:137/163
+        text = open(path).read()
+        if fmt == "fasta":
+            assert text == ">" + fn + "\n" + orig                      # output_handeler.py:37-38, no trailing \n
+        else:
+            head, rest = text.split("\n", 1)
+            assert head == "@" + fn
+            seq, qual = rest.split("+\n")                              # output_handeler.py:52-55 (no \n before +)
+            assert seq == orig and len(qual) == len(seq)
+            assert qual[:5] == "#####" and set(qual[5:-6]) == {chr(33 + 11)}   # conf 0.9167 -> Q11
+    assert open(out + "failed_reads.txt").read() == ""
+
+
+def test_failure_contract_writes_original_bases(tmp_path):
+    out = str(tmp_path) + "/o/"
+    eng = EchoEngine(fail_on=1)
+    rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1", "-e", "bad.txt"],
+                  reviser_factory=lambda args, dev: eng)
+    assert rc == 0
+    files = sorted(os.listdir(FAST5))
+    failed = open(out + "bad.txt").read().split()
+    assert failed == [files[0]]                                        # --failed_read is honoured
+    for fn in files:                                                   # both reads still produce a file
+        key = "_".join(fn.split("_")[-3:-1])
+        _, rd, _ = load_read(key)
+        orig = "".join(b.decode() for b in rd.bases.tolist())
+        assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + orig
+    # fastq fallback = the original record trimmed as extract_fastq does (nanorev_fast5_handeler.py:152-171)
+    out2 = str(tmp_path) + "/q/"
+    cli.main(["-d", FAST5, "-o", out2, "-F", "fastq", "-S", "ecoli", "--thread", "1"],
+             reviser_factory=lambda args, dev: EchoEngine(fail_on=1))
+    g, _, _ = load_read("_".join(files[0].split("_")[-3:-1]))
+    text = open(out2 + files[0].split(".")[0] + "_out.fastq").read()
+    assert text == "@" + files[0] + "\n" + bytes(g["fq_bases"]).decode() + "+\n" + bytes(g["fq_qual"]).decode()
+
+
+def test_broken_fast5_is_logged_not_fatal(tmp_path):
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "broken.fast5").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\x00" * 64)
+    out = str(tmp_path) + "/o/"
+    rc = cli.main(["-d", str(d), "-o", out, "-S", "ecoli"], reviser_factory=lambda a, dev: EchoEngine())
+    assert rc == 0 and open(out + "failed_reads.txt").read().split() == ["broken.fast5"]
+    assert not glob.glob(out + "*_out.fasta")
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_on_gpu(tmp_path, species_models):
+    from nanoreviser_amd.engine import Reviser
+    out = str(tmp_path) + "/out/"
+    assert cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--gpus", "1"]) == 0
+    rv = Reviser(*species_models["ecoli"])
+    for fn in sorted(os.listdir(FAST5)):
+        key = "_".join(fn.split("_")[-3:-1])
+        _, rd, rt = load_read(key)
+        p1, p2, a1, a2 = rv.predict_read(rt.sig_ev, rt.feat_ev)
+        want = hs.revise_read(rd.bases, a1, a2, 11)
+        text = open(out + fn.split(".")[0] + "_out.fasta").read()
+        assert text == ">" + fn + "\n" + want
+        orig = "".join(b.decode() for b in rd.bases.tolist())
+        same = sum(x == y for x, y in zip(want, orig)) / len(orig)
+        assert 0.90 < same <= 1.0 and abs(len(want) - len(orig)) < 0.05 * len(orig)
+    assert open(out + "failed_reads.txt").read() == ""
+    rv.close()

@@ -1,0 +1,64 @@
+"""h5lite (own minimal HDF5 reader) against vectors extracted with h5py by tools/ (CPU).
+Weights: per-tensor sha256 manifests written by tools/convert_weights.py (h5py).  fast5: the
+Events / Signal / Fastq arrays stored in tests/golden/reads/*.npz by tools/make_goldens.py (h5py)."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+from nanoreviser_amd import h5lite
+from nanoreviser_amd import weights as W
+
+
+@pytest.mark.parametrize("sp", ["ecoli", "human"])
+@pytest.mark.parametrize("m", [1, 2])
+def test_keras_weight_files(sp, m):
+    path = os.path.join(ROOT, "model", sp, f"{sp}_win13_50ep_model{m}.h5")      # NanoReviser.py:191-193
+    man = json.load(open(os.path.join(GOLD, "weights", f"{sp}_win13_50ep_model{m}.json")))
+    ts = h5lite.read_keras_weights(path)
+    assert len(ts) == 60
+    for t, ent in zip(ts, man["tensors"]):
+        assert list(t.shape) == ent["shape"] and t.dtype == np.float32
+        assert hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() == ent["sha256"], ent["role"]
+    f = h5lite.File(path)
+    assert f.attrs["keras_version"] in (b"2.2.4", "2.2.4") and f.attrs["backend"] in (b"tensorflow", "tensorflow")
+    assert len(f.attrs["layer_names"]) == 31 or len(f.attrs["layer_names"]) > 20
+    mw = W.load_model(path)
+    assert (mw.T, mw.n_class) == (11, 6 if m == 1 else 5)
+    assert hashlib.sha256(mw.flat().tobytes()).hexdigest() == man["blob_sha256"]
+
+
+def test_fast5_files_match_h5py_extraction():
+    files = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")))
+    assert len(files) == 2
+    for p in files:
+        key = "_".join(os.path.basename(p).split("_")[-3:-1])
+        g = np.load(os.path.join(GOLD, "reads", key + ".npz"))
+        d = h5lite.read_fast5(p)
+        ev = d["events"]
+        assert ev.dtype.names == ("mean", "start", "stdv", "length", "model_state", "move",
+                                  "p_model_state", "weights")
+        for col in ("mean", "start", "stdv", "length", "model_state", "move"):
+            assert np.array_equal(ev[col], g["ev_" + col]), col
+        assert d["signal"].dtype == np.int16 and np.array_equal(d["signal"], g["raw_signal"])
+        assert d["fastq"] == bytes(g["fastq"])
+        assert d["version"] == bytes(g["albacore_version"]).decode() == "2.0.2"   # vlen string attribute
+        assert int(d["raw_attrs"]["read_number"]) == int(key.split("read")[1])
+    f = h5lite.File(files[0])
+    assert sorted(f.keys()) == ["Analyses", "Raw", "UniqueGlobalKey"]
+    assert f["UniqueGlobalKey/channel_id"].attrs["sampling_rate"] == 4000.0
+    with pytest.raises(KeyError):
+        f["/Analyses/Basecall_1D_999"]
+    with pytest.raises(RuntimeError):
+        h5lite.read_fast5(files[0], basecall_group="Basecall_1D_999")
+
+
+def test_rejects_non_hdf5(tmp_path):
+    p = tmp_path / "x.fast5"
+    p.write_bytes(b"not hdf5 at all" * 10)
+    with pytest.raises(h5lite.H5Error):
+        h5lite.File(str(p))
