@@ -108,6 +108,20 @@ static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
       });
 }
 
+// Dense (K x N row-major) for the 16x16x4 MFMA: [ct][kg][64][4], K multiple of 16,
+//   pack[lane][j] = W[16*kg + 4*(lane>>4) + j][16*ct + (lane&15)]
+static void pack_dense16(const float* W, int K, int N, std::vector<float>& out) {
+  const int CT = (N + 15) / 16, KG = (K + 15) / 16;
+  out.assign((size_t)CT * KG * 256, 0.f);
+  for (int ct = 0; ct < CT; ++ct)
+    for (int kg = 0; kg < KG; ++kg)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          int k = 16 * kg + 4 * (lane >> 4) + j, col = 16 * ct + (lane & 15);
+          out[((size_t)ct * KG + kg) * 256 + lane * 4 + j] = (k < K && col < N) ? W[(size_t)k * N + col] : 0.f;
+        }
+}
+
 // Keras inference BatchNorm as scale/shift:  x*inv + (beta - mean*inv), inv = gamma/sqrt(var+eps)
 static void bn_fold(const float* g, const float* be, const float* mu, const float* var, int n,
                     float* scale, float* shift) {
@@ -186,7 +200,7 @@ static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
     d.conv = put(cv, 264);
   }
   std::vector<float> wp, bs;
-  pack_dense(b.t(32), 400, 64, wp);
+  pack_dense16(b.t(32), 400, 64, wp);
   d.dpack = put(wp.data(), wp.size());
   d.dbias = put(b.t(33), 64);
   const int lbase[4] = {12, 22, 34, 44}, lK[4] = {6, 32, 192, 256}, lH[4] = {16, 64, 128, 64};
@@ -328,7 +342,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     a.signal = d_sig;
     if (read_mode) { a.T = 1; a.n_rows = n + T - 1; }
     else { a.T = T; a.n_rows = n; }
-    int blocks = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
+    a.n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
+    a.dbg = h->dbg;
+    // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
+    int blocks = a.n_tiles < 128 ? a.n_tiles : 128;
     hipLaunchKernelGGL(cnn_kernel, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     if ((rc = mark(1))) return rc;
   }
