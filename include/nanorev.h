@@ -70,7 +70,11 @@ int nrv_predict_read(nrv_handle* h, const float* sig_ev, const float* feat_ev, i
                      float* p1, float* p2, int8_t* a1, int8_t* a2);
 
 /* Same two calls with DEVICE pointers, enqueued on the handle's stream without a host sync
- * (call nrv_sync, or synchronise the stream you passed to nrv_set_stream). */
+ * (call nrv_sync, or synchronise the stream you passed to nrv_set_stream).  The inputs must be
+ * complete in stream order.  The handle's own stream is a blocking stream, i.e. it is ordered
+ * after work already queued on the legacy default stream (where e.g. torch produces tensors by
+ * default); producers on any other stream must be synchronised by the caller, or the handle
+ * pointed at that stream with nrv_set_stream. */
 int nrv_predict_device(nrv_handle* h, const float* d_signal, const float* d_read, int64_t n,
                        float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2);
 int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d_feat_ev,

@@ -458,7 +458,9 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
       for (int i = 0; i < 4; ++i) h->geo[i] = (r[i] >= 0 && r[i] < 5) ? r[i] : 0;
   }
   int rc = NRV_OK;
-  e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  // a BLOCKING stream: it orders itself against the legacy default stream, so inputs produced on
+  // the default stream (torch's default) are complete before our first kernel reads them
+  e = hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault);
   if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete h; return NRV_E_HIP; }
   h->stream = h->own_stream;
   if ((rc = upload_model(h, 0, b1, 6)) || (rc = upload_model(h, 1, b2, 5)) || (rc = ensure_workspace(h))) {

@@ -199,6 +199,8 @@ def test_full_size_properties_device_api(species_models):
     m1, m2 = species_models["ecoli"]
     T, n = 13, 1 << 20
     rv = Reviser(m1.with_window(T), m2.with_window(T), batch=4096)
+    # device-pointer calls are asynchronous on the handle's stream, which is ordered after the
+    # default stream torch produces these inputs on
     g = torch.Generator(device="cuda").manual_seed(1234)
     sig = (torch.randn(n, T, 50, device="cuda", generator=g) * 1.36 - 0.10).clamp_(-8.4, 4.8)
     feat = torch.rand(n, T, 6, device="cuda", generator=g)
@@ -211,6 +213,7 @@ def test_full_size_properties_device_api(species_models):
         a1 = torch.empty(k, dtype=torch.int8, device="cuda"); a2 = torch.empty(k, dtype=torch.int8, device="cuda")
         rvx.predict_device(s.data_ptr(), f.data_ptr(), k, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
         rvx.sync()
+        torch.cuda.synchronize()
         return p1, p2, a1, a2
 
     o = run(sig, feat, rv)
