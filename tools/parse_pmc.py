@@ -19,7 +19,7 @@ def short(name):
     if m:
         return {"0, 0, 16": "lstm1", "8, 0, 64": "lstm2", "32, 16, 128": "lstm3", "64, 0, 64": "lstm4"}.get(
             ", ".join(m.groups()), name)
-    for k in ("cnn_kernel", "head_kernel"):
+    for k in ("cnn_kernel", "head_mlp_kernel", "head_final_kernel", "head_kernel"):
         if k in name:
             return k
     return None
