@@ -17,7 +17,7 @@ Changed on purpose:
   * no tmp-dir copies (the -t flag is accepted and ignored; the reference's per-slot tmp dirs race,
     :111) and no file is dropped when the count is not a multiple of the pool size (:212);
   * reads are sharded over the visible GPUs, one worker process per GPU, no collectives
-    (--gpus, default all); --thread bounds the host-side parsing threads per worker;
+    (--gpus, default all); --thread bounds the host-stage worker processes per GPU worker;
   * explicitly given --model{1,2}_predict_dir win over -S (in the reference -S always overrides
     them, which makes those flags dead, :191-193).
 FASTQ qualities: the reviser has no Guppy qualities; each revised base gets
@@ -30,7 +30,7 @@ import math
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -118,28 +118,60 @@ def phred_chars(p1: np.ndarray, p2: np.ndarray) -> np.ndarray:
     return (q + 33).astype(np.uint8)
 
 
-def revise_one(reviser, rd: hs.ReadData):
-    """One read through the engine -> (revised sequence, per-base quality string)."""
-    rt = hs.read_tensors(rd)
-    p1, p2, a1, a2 = reviser.predict_read(rt.sig_ev, rt.feat_ev)
-    T = reviser.T
-    seq = hs.revise_read(rd.bases, a1, a2, T)
-    # qualities follow the same merge walk
+def _finish_read(T: int, rt: hs.ReadTensors, p1, p2, a1, a2):
+    """Calls of one read -> (revised sequence, per-base quality string)."""
+    codes = np.frombuffer(np.asarray(rt.bases, dtype="S1").tobytes(), dtype=np.uint8)
     off, n = (T - 1) // 2, len(a1)
-    qc = phred_chars(p1, p2) if n else np.zeros(0, np.uint8)
-    qual: List[int] = [ord("#")] * min(off, len(rd.bases))
-    l1 = np.asarray(a1).astype(np.int64)
-    l2 = np.asarray(a2).astype(np.int64) + 1
-    for i in range(n):
-        x, y = hs.LABEL_TO_BASE[int(l1[i])], hs.LABEL_TO_BASE[int(l2[i])]
-        if x == "D" and y in hs._ACGT:
-            qual.extend((int(qc[i]), int(qc[i])))
-        elif x == "-" and y == "-":
-            continue
-        else:
-            qual.append(int(qc[i]))
-    qual.extend([ord("#")] * (len(seq) - len(qual)))
-    return seq, bytes(qual[:len(seq)]).decode("ascii")
+    if n == 0:
+        return codes.tobytes().decode("ascii"), "#" * len(codes)
+    first, second, count = hs.merge_calls(codes[off:off + n], a1, a2)
+    qc = phred_chars(p1, p2)
+    seq_mid, q_mid = hs.expand_calls(first, second, count, qc, qc)
+    edge = np.full(1, ord("#"), np.uint8)
+    seq = codes[:off].tobytes() + seq_mid.tobytes() + codes[off + n:].tobytes()
+    qual = np.repeat(edge, off).tobytes() + q_mid.tobytes() + np.repeat(edge, len(codes) - off - n).tobytes()
+    return seq.decode("ascii"), qual.decode("ascii")
+
+
+def revise_one(reviser, rt: hs.ReadTensors):
+    """One read through the engine -> (revised sequence, per-base quality string)."""
+    p1, p2, a1, a2 = reviser.predict_read(rt.sig_ev, rt.feat_ev)
+    return _finish_read(reviser.T, rt, p1, p2, a1, a2)
+
+
+def revise_many(reviser, rts: Sequence[hs.ReadTensors]):
+    """Several reads in ONE device call: their per-event arrays are concatenated, the engine forms
+    every sliding window of the concatenation, and the T windows that straddle each read boundary
+    are simply not used (0.2 % extra work; full launch groups, one host<->device round trip)."""
+    if len(rts) == 1:
+        return [revise_one(reviser, rts[0])]
+    T = reviser.T
+    sig = np.concatenate([rt.sig_ev for rt in rts])
+    feat = np.concatenate([rt.feat_ev for rt in rts])
+    p1, p2, a1, a2 = reviser.predict_read(sig, feat)
+    out, e0 = [], 0
+    for rt in rts:
+        N = len(rt.feat_ev)
+        n = max(N - T, 0)
+        sl = slice(e0, e0 + n)                     # window i of the read == window e0+i of the batch
+        out.append(_finish_read(T, rt, p1[sl], p2[sl], a1[sl], a2[sl]))
+        e0 += N
+    return out
+
+
+def _load_one(job):
+    """Worker-process side of the host stage: fast5 -> per-event device inputs (picklable)."""
+    path, fn, group, subgroup = job
+    t0 = time.perf_counter()
+    try:
+        rd, fq = parse_read(path, group, subgroup)
+    except Exception as e:                           # broken file: nothing to fall back to
+        return fn, None, None, repr(e), time.perf_counter() - t0
+    try:
+        rt = hs.read_tensors(rd)
+        return fn, rt, fq, None, time.perf_counter() - t0
+    except Exception as e:                           # segmentation failed: originals can still be written
+        return fn, hs.ReadTensors(None, None, rd.bases, 0.0, 0.0), fq, repr(e), time.perf_counter() - t0
 
 
 def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
@@ -153,60 +185,99 @@ def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
 
 
 def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None]) -> dict:
-    """Revise `files` (names inside args.fast5_base_dir) with one engine.  Returns counters."""
+    """Revise `files` (names inside args.fast5_base_dir) with one engine.  The host stage (HDF5
+    parsing, event collapse, signal segmentation) runs in worker PROCESSES (--thread of them, capped
+    at the core count) that stay a bounded number of reads ahead of the device."""
     stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
-    nthreads = max(1, min(int(args.thread), os.cpu_count() or 1, 32))
+    nworkers = max(1, min(int(args.thread), os.cpu_count() or 1, 32, max(1, len(files))))
+    jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup)
+            for fn in files]
 
-    def load(fn):
+    def results():
+        if nworkers == 1 or len(files) < 4:
+            for j in jobs:
+                yield _load_one(j)
+            return
+        import multiprocessing as mp
+        from collections import deque
+        with ProcessPoolExecutor(nworkers, mp_context=mp.get_context("spawn")) as pool:
+            pend, it = deque(), iter(jobs)
+            for j in it:
+                pend.append(pool.submit(_load_one, j))
+                if len(pend) >= 4 * nworkers:
+                    yield pend.popleft().result()
+            while pend:
+                yield pend.popleft().result()
+
+    def fallback(fn, rt, fq, e):                      # NanoReviser.py:146-152 / :173-179
+        stats["failed"].append(fn)
+        log(f"[！！！Error] revising {fn.split('.')[0]}: {e}; writing the original basecalls")
+        try:
+            if args.output_format == "fastq" and fq is not None:
+                b, q = hs.trim_fastq(fq)
+                write_read(args, fn, b, q)
+            else:
+                orig = "".join(x.decode() for x in np.asarray(rt.bases).tolist())
+                write_read(args, fn, orig, None)
+        except Exception as e2:
+            log(f"[！！！Error] stroring : {fn.split('.')[0]}_out.{args.output_format}...... {e2}")
+
+    def run_batch(batch):
+        """Engine thread: one device call for the batch, then merge + write per read."""
         t0 = time.perf_counter()
         try:
-            return fn, parse_read(os.path.join(args.fast5_base_dir, fn), args.basecall_group,
-                                  args.basecall_subgroup), None, time.perf_counter() - t0
-        except Exception as e:                       # broken file: nothing to fall back to
-            return fn, None, e, time.perf_counter() - t0
-
-    def bounded_map(pool, fn, items, depth):
-        """pool.map with at most `depth` parsed reads in flight (a read is ~1 MB of arrays)."""
-        from collections import deque
-        pend, it = deque(), iter(items)
-        for x in it:
-            pend.append(pool.submit(fn, x))
-            if len(pend) >= depth:
-                yield pend.popleft().result()
-        while pend:
-            yield pend.popleft().result()
-
-    with ThreadPoolExecutor(nthreads) as pool:
-        for fn, parsed, err, dt in bounded_map(pool, load, files, 4 * nthreads):
-            stats["host_s"] += dt
-            if parsed is None:
-                log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {err}")
-                stats["failed"].append(fn)
+            outs = revise_many(reviser, [rt for _, rt, _ in batch])
+        except Exception:
+            outs = []
+            for fn, rt, fq in batch:                 # isolate the failing read(s)
+                try:
+                    outs.append(revise_one(reviser, rt))
+                except Exception as e:
+                    outs.append(e)
+        stats["engine_s"] += time.perf_counter() - t0
+        for (fn, rt, fq), o in zip(batch, outs):
+            if isinstance(o, Exception):
+                fallback(fn, rt, fq, o)
                 continue
-            rd, fq = parsed
             try:
-                t0 = time.perf_counter()
-                seq, qual = revise_one(reviser, rd)
-                stats["engine_s"] += time.perf_counter() - t0
-                write_read(args, fn, seq, qual)
-                stats["bases"] += len(seq)
+                write_read(args, fn, o[0], o[1])
+                stats["bases"] += len(o[0])
                 if not args.test_mode:
                     log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved......")
                 else:
                     log("INFO Congratulations, NanoReviser is installed properly")
-            except Exception as e:                   # NanoReviser.py:146-152 / :173-179
-                stats["failed"].append(fn)
-                log(f"[！！！Error] revising {fn.split('.')[0]}: {e}; writing the original basecalls")
-                try:
-                    if args.output_format == "fastq" and fq is not None:
-                        b, q = hs.trim_fastq(fq)
-                        write_read(args, fn, b, q)
-                    else:
-                        orig = "".join(x.decode() for x in rd.bases.tolist())
-                        write_read(args, fn, orig, None)
-                except Exception as e2:
-                    log(f"[！！！Error] stroring : {fn.split('.')[0]}_out.{args.output_format}...... {e2}")
+            except Exception as e:
+                fallback(fn, rt, fq, e)
+
+    # reads are grouped into device calls of >= kBatchEvents events; the engine runs in its own
+    # thread (the C-ABI call releases the GIL) so unpickling the next reads overlaps the device
+    kBatchEvents = 8 * max(int(getattr(args, "batch", 4096)), 1024)
+    from concurrent.futures import ThreadPoolExecutor
+    from collections import deque
+    inflight = deque()
+    with ThreadPoolExecutor(1) as eng:
+        batch, nev = [], 0
+        for fn, rt, fq, err, dt in results():
+            stats["host_s"] += dt
             stats["reads"] += 1
+            if rt is None:
+                log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {err}")
+                stats["failed"].append(fn)
+                continue
+            if err is not None:
+                fallback(fn, rt, fq, err)
+                continue
+            batch.append((fn, rt, fq))
+            nev += len(rt.feat_ev)
+            if nev >= kBatchEvents:
+                inflight.append(eng.submit(run_batch, batch))
+                batch, nev = [], 0
+                while len(inflight) > 2:
+                    inflight.popleft().result()
+        if batch:
+            inflight.append(eng.submit(run_batch, batch))
+        while inflight:
+            inflight.popleft().result()
     return stats
 
 

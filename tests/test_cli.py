@@ -19,12 +19,14 @@ class EchoEngine:
     every window centre (model1 label, model2 label-1), so revise_read must return the input."""
     T = 11
 
-    def __init__(self, fail_on=None):
-        self.fail_on, self.calls = fail_on, 0
+    def __init__(self, fail_marker=None):
+        self.fail_marker, self.calls = fail_marker, 0
 
     def predict_read(self, sig_ev, feat_ev):
         self.calls += 1
-        if self.fail_on is not None and self.calls == self.fail_on:
+        # fails on every call whose first event is the marked read's first event: the batched call
+        # (marked read first) AND the per-read retry of that read, but not the other reads' retries
+        if self.fail_marker is not None and np.array_equal(feat_ev[0], self.fail_marker):
             raise RuntimeError("injected engine failure")
         assert sig_ev.dtype == np.float32 and sig_ev.shape[1] == 50 and feat_ev.shape[1] == 6
         n = len(feat_ev) - self.T
@@ -97,11 +99,12 @@ def test_file_contract_with_echo_engine(tmp_path, fmt):
 
 def test_failure_contract_writes_original_bases(tmp_path):
     out = str(tmp_path) + "/o/"
-    eng = EchoEngine(fail_on=1)
+    files = sorted(os.listdir(FAST5))
+    _, _, rt0 = load_read("_".join(files[0].split("_")[-3:-1]))
+    eng = EchoEngine(fail_marker=rt0.feat_ev[0])
     rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1", "-e", "bad.txt"],
                   reviser_factory=lambda args, dev: eng)
-    assert rc == 0
-    files = sorted(os.listdir(FAST5))
+    assert rc == 0 and eng.calls == 3                                  # batch, retry read 0, retry read 1
     failed = open(out + "bad.txt").read().split()
     assert failed == [files[0]]                                        # --failed_read is honoured
     for fn in files:                                                   # both reads still produce a file
@@ -112,7 +115,7 @@ def test_failure_contract_writes_original_bases(tmp_path):
     # fastq fallback = the original record trimmed as extract_fastq does (nanorev_fast5_handeler.py:152-171)
     out2 = str(tmp_path) + "/q/"
     cli.main(["-d", FAST5, "-o", out2, "-F", "fastq", "-S", "ecoli", "--thread", "1"],
-             reviser_factory=lambda args, dev: EchoEngine(fail_on=1))
+             reviser_factory=lambda args, dev: EchoEngine(fail_marker=rt0.feat_ev[0]))
     g, _, _ = load_read("_".join(files[0].split("_")[-3:-1]))
     text = open(out2 + files[0].split(".")[0] + "_out.fastq").read()
     assert text == "@" + files[0] + "\n" + bytes(g["fq_bases"]).decode() + "+\n" + bytes(g["fq_qual"]).decode()

@@ -144,3 +144,32 @@ def test_revise_read_rules():
     a1[3], a2[3] = lab["C"], lab["G"] - 1
     assert hs.revise_read(bases, a1, a2, T) == "ACGTACGTACGTACG"
     assert hs.revise_read(bases[:5], [], [], T) == "ACGTA"
+
+
+def test_vectorised_merge_equals_rule_by_rule_loop():
+    """hoststage.merge_calls/expand_calls (NumPy) against a plain per-window loop over the rules."""
+    def loop(bases, a1, a2, T):
+        b = [x.decode() for x in bases.tolist()]
+        off, n, out = (T - 1) // 2, len(a1), []
+        out += b[:off]
+        for i in range(n):
+            x, y = hs.LABEL_TO_BASE[int(a1[i])], hs.LABEL_TO_BASE[int(a2[i]) + 1]
+            if x == y and x in "ATCG":
+                out.append(x)
+            elif x == "D" and y in "ATCG":
+                out += [b[i + off], y]
+            elif x == "-" and y == "-":
+                continue
+            else:
+                out.append(b[i + off])
+        return "".join(out + b[off + n:])
+
+    rng = np.random.default_rng(0)
+    for N in (12, 14, 30, 500, 5000):
+        for T in (11, 13):
+            if N <= T:
+                continue
+            bases = np.array(list("ACGT"), dtype="S1")[rng.integers(0, 4, N)]
+            a1 = rng.integers(0, 6, N - T).astype(np.int8)
+            a2 = rng.integers(0, 5, N - T).astype(np.int8)
+            assert hs.revise_read(bases, a1, a2, T) == loop(bases, a1, a2, T)
