@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--species", default="ecoli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--prof-all", action="store_true",
+                    help="time every kernel (7 event records per step) instead of only the dominant one")
     args = ap.parse_args()
 
     import torch
@@ -245,7 +247,7 @@ def main():
         sys.exit(f"bench.py: HIP path disagrees with the oracle (max|dp|={dp:.2e}); refusing to time it")
 
     if not args.no_prof:
-        rv.prof_enable(True)
+        rv.prof_enable(1 if args.prof_all else 2)
         rv.prof_read()
     for _ in range(args.warmup):
         step()
@@ -275,7 +277,7 @@ def main():
     if d.rank == 0:
         if prof:
             names = list(prof.keys())
-            per_kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in prof.items()}
+            per_kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in prof.items() if c > 0}
             k3 = names[3]
             avg_s = prof[k3][0] / max(prof[k3][1], 1) * 1e-3
             fl = flop_lstm3_launch(T, B, executed=True)

@@ -159,7 +159,7 @@ struct nrv_handle {
   int geo[4] = {2, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
-  bool prof = false;
+  int prof = 0;                      // 0 off, 1 every kernel, 2 only slot 3 (lstm3, the dominant kernel)
   std::vector<hipEvent_t> ev_pool;   // groups of NRV_N_KERNELS+1 events
   size_t ev_used = 0;
   double prof_ms[NRV_N_KERNELS] = {0};
@@ -322,10 +322,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     }
     ev = h->ev_pool.data() + h->ev_used;
     h->ev_used += NRV_N_KERNELS + 1;
-    HIPCHK(h, hipEventRecord(ev[0], h->stream));
+    if (h->prof == 1) HIPCHK(h, hipEventRecord(ev[0], h->stream));
   }
   auto mark = [&](int k) -> int {
-    if (ev) HIPCHK(h, hipEventRecord(ev[k], h->stream));
+    if (ev && (h->prof == 1 || k == 3 || k == 4)) HIPCHK(h, hipEventRecord(ev[k], h->stream));
     return NRV_OK;
   };
   int rc;
@@ -410,6 +410,7 @@ static int prof_collect(nrv_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (size_t g = 0; g + NRV_N_KERNELS + 1 <= h->ev_used; g += NRV_N_KERNELS + 1)
     for (int k = 0; k < NRV_N_KERNELS; ++k) {
+      if (h->prof != 1 && k != 3) continue;
       float ms = 0.f;
       HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[g + k], h->ev_pool[g + k + 1]));
       h->prof_ms[k] += ms;
@@ -580,7 +581,7 @@ int nrv_prof_enable(nrv_handle* h, int on) {
   int rc = check_handle(h);
   if (rc) return rc;
   if ((rc = prof_collect(h))) return rc;
-  h->prof = on != 0;
+  h->prof = on == 2 ? 2 : (on != 0);
   return NRV_OK;
 }
 

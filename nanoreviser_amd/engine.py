@@ -236,8 +236,9 @@ class Reviser:
     def sync(self):
         self._check(self._lib.nrv_sync(self._h))
 
-    def prof_enable(self, on: bool = True):
-        self._check(self._lib.nrv_prof_enable(self._h, 1 if on else 0))
+    def prof_enable(self, on=True):
+        """True/1: every kernel; 2: only the dominant kernel (lstm3); False/0: off."""
+        self._check(self._lib.nrv_prof_enable(self._h, int(on)))
 
     def prof_read(self):
         ms = (C.c_double * N_KERNELS)()

@@ -251,3 +251,53 @@ def test_full_size_properties_device_api(species_models):
         assert torch.equal(w[0], p1[base:base + 20_000]) and torch.equal(w[1], p2[base:base + 20_000])
         assert torch.equal(w[2], a1[base:base + 20_000]) and torch.equal(w[3], a2[base:base + 20_000])
     rv.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 16, 32])
+def test_other_window_lengths_vs_oracle(species_models, T):
+    """The engine is parametric in T (1..32); only `feature.kernel` depends on T, so
+    every T runs the shipped weights + the seeded synthetic feature kernel, checked against the
+    oracle built from the same tensors.  Covers the step-loop edges (T=1: no recurrent product at
+    all; T=2: one; T=32: the largest head buffers)."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["ecoli"]
+    a, b = m1.with_window(T), m2.with_window(T)
+    sig, rd = O.synth_windows(70, T, seed=100 + T)
+    rv = Reviser(a, b)
+    p1, p2, a1, a2 = rv.predict_pair(sig, rd)
+    q1, q2, _, _ = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float64)
+    assert np.abs(p1 - q1).max() <= 1e-4 and np.abs(p2 - q2).max() <= 1e-4
+    assert_argmax(a1, q1, 1e-4, f"T={T} m1")
+    assert_argmax(a2, q2, 1e-4, f"T={T} m2")
+    # read mode at this T
+    N = 70 + T
+    rng = np.random.default_rng(T)
+    sig_ev = np.clip(rng.normal(-0.1, 1.36, (N, 50)), -8.4, 4.8).astype(np.float32)
+    feat_ev = np.abs(rng.normal(0.5, 0.3, (N, 6))).astype(np.float32)
+    r = rv.predict_read(sig_ev, feat_ev)
+    sw, fw = hs.sliding_windows(sig_ev, feat_ev, T)
+    w = rv.predict_pair(np.ascontiguousarray(sw), np.ascontiguousarray(fw))
+    assert r[0].shape == (N - T, 6)
+    for x, y in zip(r, w):
+        assert np.array_equal(x, y)
+    rv.close()
+    with pytest.raises(Exception):
+        Reviser(m1.with_window(33), m2.with_window(33))      # NRV_E_INVALID: T out of range
+
+
+def test_set_batch_grows_workspace_and_multiple_handles(species_models):
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["ecoli"]
+    sig, rd = O.synth_windows(9000, 11, seed=5)
+    rv_small = Reviser(m1, m2, batch=256)
+    rv_big = Reviser(m1, m2)                      # two live handles on one GPU
+    a = rv_small.predict_pair(sig, rd)
+    rv_small.set_batch(8192)                      # grows the workspace in place
+    b = rv_small.predict_pair(sig, rd)
+    c = rv_big.predict_pair(sig, rd, batch_size=3000)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    rv_small.close(); rv_big.close()
+    rv_small.close()                              # idempotent
