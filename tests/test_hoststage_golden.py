@@ -173,3 +173,20 @@ def test_vectorised_merge_equals_rule_by_rule_loop():
             a1 = rng.integers(0, 6, N - T).astype(np.int8)
             a2 = rng.integers(0, 5, N - T).astype(np.int8)
             assert hs.revise_read(bases, a1, a2, T) == loop(bases, a1, a2, T)
+
+
+def test_f32_window_fast_path_equals_cast_of_reference_matrix(reads):
+    """read_tensors feeds the device from segment_windows_f32 (int16 -> f32 through a value table);
+    it must be bit-identical to float32(reference f64 window matrix), the cast Keras does at feed."""
+    for key in reads.keys:
+        _, rd, rt = reads(key)
+        sig = rd.signal[rd.abs_event_start:]
+        win, m, s, shift, scale = hs.signal_segmentation(sig, rd.start, int(rd.length[-1]))
+        assert rt.sig_ev.dtype == np.float32 and np.array_equal(rt.sig_ev, win.astype(np.float32))
+        m2, s2, sh2, sc2 = hs.event_stats(sig, rd.start, int(rd.length[-1]))
+        assert np.array_equal(m, m2) and np.array_equal(s, s2) and (sh2, sc2) == (shift, scale)
+    raw = (np.arange(30) * 7 % 23 + 400).astype(np.int16)
+    st = np.array([0, 3, 11, 27])
+    w64, _, _, shift, scale = hs.signal_segmentation(raw, st, 3)
+    assert np.array_equal(hs.segment_windows_f32(raw, st, shift, scale), w64.astype(np.float32))
+    assert np.array_equal(hs.segment_windows_f32(raw.astype(np.float64), st, shift, scale), w64.astype(np.float32))
