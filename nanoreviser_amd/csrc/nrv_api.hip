@@ -96,6 +96,35 @@ static void pack_lstm(const Blob& b, int base, int Kin, int H, std::vector<float
   }
 }
 
+// lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
+//   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
+//   recurrent step s (0..3): U[unit = 4*(lane>>4) + s][g*16 + (lane&15)]  (lane quarter q holds the
+//                            A values h[row][4q..4q+3], so k-step s pairs unit 4q+s)
+static void pack_lstm1_16(const Blob& b, int base, std::vector<float>& wpack, std::vector<float>& bias) {
+  const int H = 16, Kin = 6;
+  wpack.assign((size_t)2 * 6 * 4 * 64, 0.f);
+  bias.assign((size_t)2 * 4 * 16, 0.f);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);
+    const float* U = b.t(base + dir * 3 + 1);
+    const float* B = b.t(base + dir * 3 + 2);
+    for (int g = 0; g < 4; ++g) {
+      for (int lane = 0; lane < 64; ++lane) {
+        const int q = lane >> 4, c = lane & 15;
+        for (int s = 0; s < 2; ++s) {
+          int k = 4 * s + q;
+          wpack[(((size_t)dir * 6 + s) * 4 + g) * 64 + lane] = k < Kin ? W[(size_t)k * 4 * H + g * H + c] : 0.f;
+        }
+        for (int s = 0; s < 4; ++s) {
+          int u = 4 * q + s;
+          wpack[(((size_t)dir * 6 + 2 + s) * 4 + g) * 64 + lane] = U[(size_t)u * 4 * H + g * H + c];
+        }
+      }
+      for (int c = 0; c < 16; ++c) bias[((size_t)dir * 4 + g) * 16 + c] = B[g * H + c];
+    }
+  }
+}
+
 // Dense (K x N row-major) -> [ntile][kg][64][4], columns >= N zero
 static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
   const int NT = (N + 31) / 32, KG = (K + 7) / 8;
@@ -138,6 +167,7 @@ struct DevModel {
   // offsets (floats) into `all`
   size_t conv, dpack, dbias;
   size_t l_w[4], l_b[4], l_s[4], l_h[4];
+  size_t l1w16, l1b16;        // lstm1 packed for the 16x16x4 kernel
   size_t d1p, d1b, d2p, d2b, mop, mob, fw, fb, ow, ob;
   int C;
 };
@@ -156,7 +186,7 @@ struct nrv_handle {
   float *d_sig = nullptr, *d_feat = nullptr, *d_p[2] = {0, 0};
   int8_t* d_a[2] = {0, 0};
   int dbg = 0;                     // NRV_DBG timing experiments (never set in production)
-  int geo[4] = {2, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
+  int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
   int prof = 0;                      // 0 off, 1 every kernel, 2 only slot 3 (lstm3, the dominant kernel)
@@ -216,6 +246,9 @@ static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
     d.l_s[l] = put(sc.data(), sc.size());
     d.l_h[l] = put(sh.data(), sh.size());
   }
+  pack_lstm1_16(b, 12, wp, bs);
+  d.l1w16 = put(wp.data(), wp.size());
+  d.l1b16 = put(bs.data(), bs.size());
   pack_dense(b.t(50), 128, 128, wp); d.d1p = put(wp.data(), wp.size());
   d.d1b = put(b.t(51), 128);
   pack_dense(b.t(52), 128, 32, wp); d.d2p = put(wp.data(), wp.size());
@@ -360,7 +393,20 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[0], d.all + d.l_b[0], d.all + d.l_s[0], d.all + d.l_h[0],
                                ActView{}, ActView{}, d_feat, read_mode ? 1 : 0, h->X1[m]};
     }
-    launch_lstm<0, 0, 16, true>(h, a, tiles, h->geo[0]);
+    if (h->geo[0] >= 0) {
+      launch_lstm<0, 0, 16, true>(h, a, tiles, h->geo[0]);
+    } else {                                     // default: the dedicated 16x16x4 kernel
+      Lstm1Args a1;
+      a1.T = T; a1.n_rows = n;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        a1.m[m] = Lstm1ModelParams{d.all + d.l1w16, d.all + d.l1b16, d.all + d.l_s[0], d.all + d.l_h[0],
+                                   d_feat, read_mode ? 1 : 0, h->X1[m]};
+      }
+      dim3 grid((n + 63) / 64, 2, 2);
+      if (h->act == 0) hipLaunchKernelGGL(lstm1_kernel<0>, grid, dim3(256), 0, h->stream, a1);
+      else hipLaunchKernelGGL(lstm1_kernel<1>, grid, dim3(256), 0, h->stream, a1);
+    }
     if ((rc = mark(2))) return rc;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
@@ -456,7 +502,7 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
     int r[4];
     if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)
-      for (int i = 0; i < 4; ++i) h->geo[i] = (r[i] >= 0 && r[i] < 5) ? r[i] : 0;
+      for (int i = 0; i < 4; ++i) h->geo[i] = (r[i] >= (i == 0 ? -1 : 0) && r[i] < 5) ? r[i] : 0;
   }
   int rc = NRV_OK;
   // a BLOCKING stream: it orders itself against the legacy default stream, so inputs produced on
@@ -599,7 +645,7 @@ int nrv_prof_read(nrv_handle* h, double* ms_total, int64_t* launches) {
 }
 
 const char* nrv_kernel_name(int slot) {
-  static const char* names[NRV_N_KERNELS] = {"cnn_kernel", "lstm_layer_kernel<lstm1 6->16>",
+  static const char* names[NRV_N_KERNELS] = {"cnn_kernel", "lstm1_kernel 6->16",
                                              "lstm_layer_kernel<lstm2 32->64>",
                                              "lstm_layer_kernel<lstm3 192->128>",
                                              "lstm_layer_kernel<lstm4 256->64>", "head_mlp_kernel+head_final_kernel"};

@@ -47,7 +47,7 @@ for T in (13,):
     ds = torch.from_numpy(sig).cuda(); dr = torch.from_numpy(rd_).cuda()
     p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
     a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
-    for cfg, dbg in (("2,2,0,2", 0), ("2,2,0,2", 0), ("2,2,0,2", 8), ("2,2,0,2", 16), ("2,2,0,2", 24)):
+    for cfg, dbg in (("-1,2,0,2", 0), ("-1,2,0,2", 0), ("2,2,0,2", 0)):
         os.environ["NRV_GEO"] = cfg
         os.environ["NRV_DBG"] = str(dbg)
         print("DBG", dbg)
