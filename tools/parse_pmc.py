@@ -19,6 +19,8 @@ def short(name):
     if m:
         return {"0, 0, 16": "lstm1", "8, 0, 64": "lstm2", "32, 16, 128": "lstm3", "64, 0, 64": "lstm4"}.get(
             ", ".join(m.groups()), name)
+    if "lstm1_kernel" in name:
+        return "lstm1"
     for k in ("cnn_kernel", "head_mlp_kernel", "head_final_kernel", "head_kernel"):
         if k in name:
             return k
