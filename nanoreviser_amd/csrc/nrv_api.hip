@@ -183,8 +183,11 @@ struct nrv_handle {
   int cap_rows = 0;                // padded rows the workspace holds
   float *S[2] = {0, 0}, *X1[2] = {0, 0}, *X2[2] = {0, 0}, *X3[2] = {0, 0}, *MO[2] = {0, 0};
   // staging for the host-pointer entry points
-  float *d_sig = nullptr, *d_feat = nullptr, *d_p[2] = {0, 0};
-  int8_t* d_a[2] = {0, 0};
+  // two staging sets [set][..]: the upload of group g+1 (copy stream) overlaps the kernels of group g
+  float *d_sig[2] = {0, 0}, *d_feat[2] = {0, 0}, *d_p[2][2] = {{0, 0}, {0, 0}};
+  int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0};
   int dbg = 0;                     // NRV_DBG timing experiments (never set in production)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
@@ -273,12 +276,16 @@ static void free_workspace(nrv_handle* h) {
   for (int m = 0; m < 2; ++m) {
     (void)hipFree(h->S[m]); (void)hipFree(h->X1[m]); (void)hipFree(h->X2[m]); (void)hipFree(h->X3[m]);
     (void)hipFree(h->MO[m]); h->MO[m] = nullptr;
-    (void)hipFree(h->d_p[m]); (void)hipFree(h->d_a[m]);
-    h->S[m] = h->X1[m] = h->X2[m] = h->X3[m] = h->d_p[m] = nullptr;
-    h->d_a[m] = nullptr;
+    for (int st = 0; st < 2; ++st) {
+      (void)hipFree(h->d_p[st][m]); (void)hipFree(h->d_a[st][m]);
+      h->d_p[st][m] = nullptr; h->d_a[st][m] = nullptr;
+    }
+    h->S[m] = h->X1[m] = h->X2[m] = h->X3[m] = nullptr;
   }
-  (void)hipFree(h->d_sig); (void)hipFree(h->d_feat);
-  h->d_sig = h->d_feat = nullptr;
+  for (int st = 0; st < 2; ++st) {
+    (void)hipFree(h->d_sig[st]); (void)hipFree(h->d_feat[st]);
+    h->d_sig[st] = h->d_feat[st] = nullptr;
+  }
   h->cap_rows = 0;
 }
 
@@ -302,11 +309,15 @@ static int ensure_workspace(nrv_handle* h) {
     HIPCHK(h, hipMemset(h->X1[m], 0, n1 * 4));
     HIPCHK(h, hipMemset(h->X2[m], 0, n2 * 4));
     HIPCHK(h, hipMemset(h->X3[m], 0, n3 * 4));
-    HIPCHK(h, hipMalloc(&h->d_p[m], (size_t)rows * 8 * 4));
-    HIPCHK(h, hipMalloc(&h->d_a[m], (size_t)rows));
+    for (int st = 0; st < 2; ++st) {
+      HIPCHK(h, hipMalloc(&h->d_p[st][m], (size_t)rows * 8 * 4));
+      HIPCHK(h, hipMalloc(&h->d_a[st][m], (size_t)rows));
+    }
   }
-  HIPCHK(h, hipMalloc(&h->d_sig, (size_t)rows * T * kSig * 4 + 4096));
-  HIPCHK(h, hipMalloc(&h->d_feat, (size_t)rows * T * kFeat * 4 + 4096));
+  for (int st = 0; st < 2; ++st) {
+    HIPCHK(h, hipMalloc(&h->d_sig[st], (size_t)rows * T * kSig * 4 + 4096));
+    HIPCHK(h, hipMalloc(&h->d_feat[st], (size_t)rows * T * kFeat * 4 + 4096));
+  }
   h->cap_rows = rows;
   return NRV_OK;
 }
@@ -435,8 +446,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   {
     HeadArgs a;
     a.T = T; a.n_rows = n;
-    float* dp[2] = {d_p1 ? d_p1 : h->d_p[0], d_p2 ? d_p2 : h->d_p[1]};
-    int8_t* da[2] = {d_a1 ? d_a1 : h->d_a[0], d_a2 ? d_a2 : h->d_a[1]};
+    float* dp[2] = {d_p1 ? d_p1 : h->d_p[0][0], d_p2 ? d_p2 : h->d_p[0][1]};
+    int8_t* da[2] = {d_a1 ? d_a1 : h->d_a[0][0], d_a2 ? d_a2 : h->d_a[0][1]};
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
       a.m[m] = HeadModelParams{d.all + d.d1p, d.all + d.d1b, d.all + d.d2p, d.all + d.d2b,
@@ -510,6 +521,11 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   e = hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault);
   if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete h; return NRV_E_HIP; }
   h->stream = h->own_stream;
+  bool ok = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int st = 0; st < 2 && ok; ++st)
+    ok = hipEventCreateWithFlags(&h->ev_in[st], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_done[st], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { g_create_error = "nrv_create: could not create the copy stream / events"; nrv_destroy(h); return NRV_E_HIP; }
   if ((rc = upload_model(h, 0, b1, 6)) || (rc = upload_model(h, 1, b2, 5)) || (rc = ensure_workspace(h))) {
     g_create_error = h->err;
     nrv_destroy(h);
@@ -526,6 +542,11 @@ void nrv_destroy(nrv_handle* h) {
   free_workspace(h);
   for (int m = 0; m < 2; ++m) (void)hipFree(h->dm[m].all);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  for (int st = 0; st < 2; ++st) {
+    if (h->ev_in[st]) (void)hipEventDestroy(h->ev_in[st]);
+    if (h->ev_done[st]) (void)hipEventDestroy(h->ev_done[st]);
+  }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -595,21 +616,42 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   if (n_in < 0 || (n_in > 0 && (!sig || !feat))) { h->err = "nrv_predict: bad arguments"; return NRV_E_INVALID; }
   const int T = h->T;
   const int64_t n = read_mode ? n_in - T : n_in;
-  for (int64_t s = 0; s < n; s += h->batch) {
+  // Pipeline over launch groups with two staging sets.  All copies run on the copy stream:
+  //   upload(g) -> [compute stream: wait, kernels(g), record done(g)] -> download(g-1) -> upload(g+1) ...
+  // Copies from/to pageable host memory block the host, so the download of group g-1 is issued
+  // AFTER the kernels of group g are queued: while the host sits in it (and in the next upload),
+  // the GPU is already computing group g.
+  auto download = [&](int64_t s, int nb, int st) -> int {
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_done[st], 0));
+    if (p1) HIPCHK(h, hipMemcpyAsync(p1 + s * 6, h->d_p[st][0], (size_t)nb * 6 * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    if (p2) HIPCHK(h, hipMemcpyAsync(p2 + s * 5, h->d_p[st][1], (size_t)nb * 5 * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    if (a1) HIPCHK(h, hipMemcpyAsync(a1 + s, h->d_a[st][0], (size_t)nb, hipMemcpyDeviceToHost, h->copy_stream));
+    if (a2) HIPCHK(h, hipMemcpyAsync(a2 + s, h->d_a[st][1], (size_t)nb, hipMemcpyDeviceToHost, h->copy_stream));
+    return NRV_OK;
+  };
+  int64_t g = 0, prev_s = 0;
+  int prev_nb = 0;
+  for (int64_t s = 0; s < n; s += h->batch, ++g) {
+    const int st = (int)(g & 1);
     int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
     size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
     const float* hs = sig + (read_mode ? s * kSig : s * T * kSig);
     const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
-    HIPCHK(h, hipMemcpyAsync(h->d_sig, hs, ev * kSig * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_feat, hf, ev * kFeat * 4, hipMemcpyHostToDevice, h->stream));
-    rc = run_group(h, h->d_sig, h->d_feat, nb, read_mode, nullptr, nullptr, nullptr, nullptr);
+    HIPCHK(h, hipMemcpyAsync(h->d_sig[st], hs, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_feat[st], hf, ev * kFeat * 4, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_in[st], h->copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[st], 0));
+    rc = run_group(h, h->d_sig[st], h->d_feat[st], nb, read_mode, h->d_p[st][0], h->d_p[st][1],
+                   h->d_a[st][0], h->d_a[st][1]);
     if (rc) return rc;
-    if (p1) HIPCHK(h, hipMemcpyAsync(p1 + s * 6, h->d_p[0], (size_t)nb * 6 * 4, hipMemcpyDeviceToHost, h->stream));
-    if (p2) HIPCHK(h, hipMemcpyAsync(p2 + s * 5, h->d_p[1], (size_t)nb * 5 * 4, hipMemcpyDeviceToHost, h->stream));
-    if (a1) HIPCHK(h, hipMemcpyAsync(a1 + s, h->d_a[0], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
-    if (a2) HIPCHK(h, hipMemcpyAsync(a2 + s, h->d_a[1], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffers are reused by the next group
+    HIPCHK(h, hipEventRecord(h->ev_done[st], h->stream));
+    if (g >= 1 && (rc = download(prev_s, prev_nb, st ^ 1))) return rc;
+    prev_s = s;
+    prev_nb = nb;
   }
+  if (g >= 1 && (rc = download(prev_s, prev_nb, (int)((g - 1) & 1)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return NRV_OK;
 }
 
