@@ -347,7 +347,9 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None) -> int:
         print("[s:::] All subprocesses done.")
         print("[s:::] NanoReviser time consuming:%.2f seconds" % dt)
         print(f"[s:::] {sum(s['reads'] for s in stats)} reads, {nb} bases, {len(failed)} failed, "
-              f"{nb / max(dt, 1e-9):.0f} bases/s end to end")
+              f"{nb / max(dt, 1e-9):.0f} bases/s end to end "
+              f"(host stage {sum(s['host_s'] for s in stats):.1f} s summed over workers, "
+              f"engine thread {sum(s['engine_s'] for s in stats):.1f} s)")
     return 0
 
 

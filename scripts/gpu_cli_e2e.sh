@@ -5,10 +5,10 @@ D=/tmp/nrv_e2e_in; O=/tmp/nrv_e2e_out/
 rm -rf $D $O; mkdir -p $D
 i=0
 for f in tests/golden/fast5/*.fast5; do
-  for k in $(seq 1 500); do ln -s $(realpath $f) $D/r${i}_$k.fast5; done; i=$((i+1))
+  for k in $(seq 1 ${REP:-500}); do ln -s $(realpath $f) $D/r${i}_$k.fast5; done; i=$((i+1))
 done
 ls $D | wc -l
-for th in 16 4; do
+for th in ${THREADS:-16 4}; do
   python3 NanoReviser.py -d $D -o $O -S ecoli --thread $th --batch ${BATCH:-4096} 2>&1 | grep -E "s:::|Error" | tail -4
 done
 ls $O | wc -l
