@@ -6,7 +6,7 @@
 // with Keras-2.2.4 inference semantics.  Everything is IEEE f32.
 //
 // How it is mapped (MI355X-first, not a translation of TF ops):
-//   * Every contraction runs on the exact-f32 matrix pipe, v_mfma_f32_32x32x2_f32
+//   * Every contraction runs on the exact-f32 matrix pipe, v_mfma_f32_32x32x2_f32 / 16x16x4
 //     (bitwise an fmaf chain, 64 FLOP/clk/SIMD, 157.3 TFLOP/s chip peak).
 //   * Activations between kernels live in an MFMA-native tiled layout
 //         act[tile32][t][kq][32 rows][4]      (kq = feature/4)
@@ -14,12 +14,15 @@
 //     (lanes 0-31: features 8g..8g+3 of rows 0..31, lanes 32-63: features 8g+4..8g+7) and is a
 //     single contiguous 1 KiB request.  Weights are pre-packed on the host into the matching
 //     B-fragment order, so B operands stream L2 -> VGPR with no LDS staging at all.
+//   * Seven launches per group of windows: cnn_kernel (signal branch), lstm1_kernel,
+//     lstm_layer_kernel x3 (lstm2..4), head_mlp_kernel, head_final_kernel.  Rows (windows) are
+//     independent, so every launch is (row tiles) x (directions) x (2 models) workgroups with no
+//     inter-workgroup communication.
 //   * One Bi-LSTM layer = one launch; a wave owns 32 hidden units x 4 gates x R row tiles, so
 //     i,f,g,o of one (window, unit) sit in the same lane/register and the cell update is
 //     register-local; c never leaves registers, h_t goes through a double-buffered LDS image
-//     (one barrier per step) and is written out coalesced with the following BatchNorm fused.
-//   * Rows (windows) are independent, so a launch is (row tiles) x (2 directions) x (2 models)
-//     workgroups with no inter-workgroup communication.
+//     (one barrier per step) and is written out coalesced with the following BatchNorm fused;
+//     the next step's input projection is issued while the VALU does this step's gates.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSig = 50;        // samples per event window   (output_handeler.py:202)
 constexpr int kFeat = 6;        // features per event         (output_handeler.py:203)
-constexpr int kTile = 32;       // rows per MFMA tile
 
 // ---------------------------------------------------------------------------------------
 // small device helpers
