@@ -58,15 +58,19 @@ static bool make_blob(const nrv_weights* w, int T, int C, Blob* b) {
 }
 
 // ---- B-fragment packing ---------------------------------------------------------------------
+// The unroll thresholds this file is compiled with (needed by lstm_layer_kernel) also reach the
+// HOST optimiser, which then fully unrolls the constant-bound packing loops below (an 11-minute
+// host compile).  They run once per nrv_create: keep the optimiser off them.
+#define NRV_HOST_COLD __attribute__((optnone, noinline))
 // One packed k-group for one 32-column tile: dst[lane][j] = get(k = 8*kg + 4*(lane>>5) + j, lane&31)
 template <class G>
-static void pack_kgroup(float* dst, int kg, G get) {
+NRV_HOST_COLD static void pack_kgroup(float* dst, int kg, G get) {
   for (int lane = 0; lane < 64; ++lane)
     for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = get(8 * kg + 4 * (lane >> 5) + j, lane & 31);
 }
 
 // Bi-LSTM layer: [dir][hg][kg][gate][64][4] ; bias [dir][hg][gate][32]
-static void pack_lstm(const Blob& b, int base, int Kin, int H, std::vector<float>& wpack,
+NRV_HOST_COLD static void pack_lstm(const Blob& b, int base, int Kin, int H, std::vector<float>& wpack,
                       std::vector<float>& bias) {
   const int NG = (H + 31) / 32;
   const int KG_IN = (Kin + 7) / 8, KG_REC = H / 8, KG = KG_IN + KG_REC;
@@ -96,11 +100,56 @@ static void pack_lstm(const Blob& b, int base, int Kin, int H, std::vector<float
   }
 }
 
+// ---- split-bf16 packing (lstm_split_kernel) ----------------------------------------------------
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32_host(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// [dir][hg][kb][gate][term 3][64 lanes][8 bf16], kb = input k-blocks (16 k each) then recurrent;
+// lane l holds k = 16*kb + 8*(l>>5) + j, column (gate, unit hg*32 + (l&31)).  Stored as uint16 in a
+// float vector (two per float) so it travels with the other packed tensors.
+NRV_HOST_COLD static void pack_lstm_split(const Blob& b, int base, int Kin, int H, std::vector<float>& out) {
+  const int NG = (H + 31) / 32, KB_IN = Kin / 16, KB = KB_IN + H / 16;
+  std::vector<uint16_t> w((size_t)2 * NG * KB * 4 * 3 * 64 * 8, 0);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);
+    const float* U = b.t(base + dir * 3 + 1);
+    for (int hg = 0; hg < NG; ++hg)
+      for (int kb = 0; kb < KB; ++kb)
+        for (int g = 0; g < 4; ++g)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int unit = hg * 32 + (lane & 31);
+              float v = 0.f;
+              if (unit < H) {
+                const int k = 16 * (kb < KB_IN ? kb : kb - KB_IN) + 8 * (lane >> 5) + j;
+                v = (kb < KB_IN ? W : U)[(size_t)k * 4 * H + g * H + unit];
+              }
+              float rem = v;
+              for (int tm = 0; tm < 3; ++tm) {
+                const uint16_t q = f32_to_bf16_rne(rem);
+                rem -= bf16_to_f32_host(q);
+                w[((((((size_t)(dir * NG + hg) * KB + kb) * 4 + g) * 3 + tm) * 64) + lane) * 8 + j] = q;
+              }
+            }
+  }
+  out.assign((w.size() + 1) / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+}
+
 // lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
 //   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
 //   recurrent step s (0..3): U[unit = 4*(lane>>4) + s][g*16 + (lane&15)]  (lane quarter q holds the
 //                            A values h[row][4q..4q+3], so k-step s pairs unit 4q+s)
-static void pack_lstm1_16(const Blob& b, int base, std::vector<float>& wpack, std::vector<float>& bias) {
+NRV_HOST_COLD static void pack_lstm1_16(const Blob& b, int base, std::vector<float>& wpack, std::vector<float>& bias) {
   const int H = 16, Kin = 6;
   wpack.assign((size_t)2 * 6 * 4 * 64, 0.f);
   bias.assign((size_t)2 * 4 * 16, 0.f);
@@ -126,7 +175,7 @@ static void pack_lstm1_16(const Blob& b, int base, std::vector<float>& wpack, st
 }
 
 // Dense (K x N row-major) -> [ntile][kg][64][4], columns >= N zero
-static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
+NRV_HOST_COLD static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
   const int NT = (N + 31) / 32, KG = (K + 7) / 8;
   out.assign((size_t)NT * KG * 256, 0.f);
   for (int nt = 0; nt < NT; ++nt)
@@ -139,7 +188,7 @@ static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
 
 // Dense (K x N row-major) for the 16x16x4 MFMA: [ct][kg][64][4], K multiple of 16,
 //   pack[lane][j] = W[16*kg + 4*(lane>>4) + j][16*ct + (lane&15)]
-static void pack_dense16(const float* W, int K, int N, std::vector<float>& out) {
+NRV_HOST_COLD static void pack_dense16(const float* W, int K, int N, std::vector<float>& out) {
   const int CT = (N + 15) / 16, KG = (K + 15) / 16;
   out.assign((size_t)CT * KG * 256, 0.f);
   for (int ct = 0; ct < CT; ++ct)
@@ -168,6 +217,7 @@ struct DevModel {
   size_t conv, dpack, dbias;
   size_t l_w[4], l_b[4], l_s[4], l_h[4];
   size_t l1w16, l1b16;        // lstm1 packed for the 16x16x4 kernel
+  size_t l_ws[4];             // lstm2..4 weights split into three bf16 terms (index 1..3)
   size_t d1p, d1b, d2p, d2b, mop, mob, fw, fb, ow, ob;
   int C;
 };
@@ -188,7 +238,7 @@ struct nrv_handle {
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0};
-  int dbg = 0;                     // NRV_DBG timing experiments (never set in production)
+  int split = 0;                   // bit l set: layer l (1..3 = lstm2..4) runs the split-bf16 kernel (NRV_SPLIT)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
@@ -210,7 +260,7 @@ namespace {
     }                                                                                    \
   } while (0)
 
-static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
+NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
   const int T = h->T;
   DevModel& d = h->dm[mi];
   d.C = C;
@@ -248,6 +298,10 @@ static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
               sc.data(), sh.data());
     d.l_s[l] = put(sc.data(), sc.size());
     d.l_h[l] = put(sh.data(), sh.size());
+  }
+  for (int l = 1; l < 4; ++l) {
+    pack_lstm_split(b, lbase[l], lK[l], lH[l], wp);
+    d.l_ws[l] = put(wp.data(), wp.size());
   }
   pack_lstm1_16(b, 12, wp, bs);
   d.l1w16 = put(wp.data(), wp.size());
@@ -349,6 +403,18 @@ static void launch_lstm(nrv_handle* h, const LstmArgs& a, int tiles, int geo) {
 #undef NRV_L
 }
 
+template <int KQ0, int KQ1, int H, int R, int WR>
+static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* const ws[2], int tiles) {
+  constexpr int NG = (H + 31) / 32;
+  LstmSplitArgs sa;
+  sa.T = a.T; sa.n_rows = a.n_rows;
+  for (int m = 0; m < 2; ++m)
+    sa.m[m] = LstmSplitModelParams{ws[m], a.m[m].bias, a.m[m].bn_scale, a.m[m].bn_shift, a.m[m].in0, a.m[m].in1,
+                                   a.m[m].out};
+  dim3 grid((tiles + R * WR - 1) / (R * WR), 2, 2), blk(64 * NG * WR);
+  hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);   // hard_sigmoid only
+}
+
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
 // n + T - 1 events and the windows are formed on the device.
 static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int n, bool read_mode,
@@ -387,7 +453,6 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     if (read_mode) { a.T = 1; a.n_rows = n + T - 1; }
     else { a.T = T; a.n_rows = n; }
     a.n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
-    a.dbg = h->dbg;
     // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
     int blocks = a.n_tiles < 128 ? a.n_tiles : 128;
     hipLaunchKernelGGL(cnn_kernel, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
@@ -398,7 +463,6 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   {
     LstmArgs a;
     a.T = T; a.n_rows = n;
-    a.dbg = h->dbg;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
       a.m[m] = LstmModelParams{d.all + d.l_w[0], d.all + d.l_b[0], d.all + d.l_s[0], d.all + d.l_h[0],
@@ -424,7 +488,12 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[1], d.all + d.l_b[1], d.all + d.l_s[1], d.all + d.l_h[1],
                                win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
     }
-    launch_lstm<8, 0, 64, false>(h, a, tiles, h->geo[1]);
+    if ((h->split & 2) && h->act == 0) {
+      const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
+      launch_lstm_split<8, 0, 64, 1, 2>(h, a, ws, tiles);
+    } else {
+      launch_lstm<8, 0, 64, false>(h, a, tiles, h->geo[1]);
+    }
     if ((rc = mark(3))) return rc;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
@@ -432,14 +501,24 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[2], d.all + d.l_b[2], d.all + d.l_s[2], d.all + d.l_h[2],
                                win_view(h->X2[m], 32), sv, nullptr, 0, h->X3[m]};
     }
-    launch_lstm<32, 16, 128, false>(h, a, tiles, h->geo[2]);
+    if ((h->split & 4) && h->act == 0) {
+      const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
+      launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
+    } else {
+      launch_lstm<32, 16, 128, false>(h, a, tiles, h->geo[2]);
+    }
     if ((rc = mark(4))) return rc;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
       a.m[m] = LstmModelParams{d.all + d.l_w[3], d.all + d.l_b[3], d.all + d.l_s[3], d.all + d.l_h[3],
                                win_view(h->X3[m], 64), ActView{}, nullptr, 0, h->X2[m] /* X4 aliases X2 */};
     }
-    launch_lstm<64, 0, 64, false>(h, a, tiles, h->geo[3]);
+    if ((h->split & 8) && h->act == 0) {
+      const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
+      launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
+    } else {
+      launch_lstm<64, 0, 64, false>(h, a, tiles, h->geo[3]);
+    }
     if ((rc = mark(5))) return rc;
   }
   // 5: head
@@ -509,7 +588,7 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   nrv_handle* h = new (std::nothrow) nrv_handle();
   if (!h) { g_create_error = "out of host memory"; return NRV_E_NOMEM; }
   h->device = device; h->T = T; h->act = recurrent_act;
-  if (const char* s = getenv("NRV_DBG")) h->dbg = atoi(s);
+  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s);
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
     int r[4];
     if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)

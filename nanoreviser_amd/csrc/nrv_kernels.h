@@ -25,6 +25,7 @@
 //     the next step's input projection is issued while the VALU does this step's gates.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace nrv {
@@ -135,8 +136,6 @@ struct LstmArgs {
   LstmModelParams m[2];
   int T;
   int n_rows;             // valid rows (windows)
-  int dbg;                // timing experiments only (NRV_DBG): 1 = all A reads from row tile 0,
-                          // 2 = no copy-out, 4 = no gates.  0 in production.
 };
 
 // KQ0/KQ1: input segments in 4-feature chunks (K = 4*KQ, K multiple of 8).  H: hidden units per
@@ -260,7 +259,7 @@ lstm_layer_kernel(const LstmArgs args) {
         ap0[r] = P.plain_in +
                  (P.plain_ev_stride ? (size_t)(row + t) * kFeat : ((size_t)row * T + t) * kFeat) + 4 * half;
       } else {
-        const int rb = (args.dbg & 1) ? 0 : row0 + r * 32;
+        const int rb = row0 + r * 32;
         ar0[r] = make_rsrc(P.in0.ubase(rb, t), 0xffffffffu);
         av0[r] = P.in0.voff(rb, t, l31, half) * 4;
         if constexpr (KQ1 > 0) {
@@ -373,7 +372,7 @@ lstm_layer_kernel(const LstmArgs args) {
     // The previous step's h image (hcur) is also what still has to go out to HBM: its LDS reads are
     // issued here, its BatchNorm + stores after the first k-group's MFMAs are in the pipe.
     if (s > 0) {
-      if (!(args.dbg & 2)) copyout_read(hcur);
+      copyout_read(hcur);
       const float* hp = hcur + hr_off;
       f32x4 a[2][R], b[2][4];
 #pragma unroll
@@ -395,7 +394,7 @@ lstm_layer_kernel(const LstmArgs args) {
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[g][r] = mfma32(a[cur][r][j], b[cur][g][j], acc[g][r]);
-        if (kg == 0 && !(args.dbg & 2)) copyout_write(dir ? t + 1 : t - 1);
+        if (kg == 0) copyout_write(dir ? t + 1 : t - 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -409,7 +408,7 @@ lstm_layer_kernel(const LstmArgs args) {
       inproj(acc, preA, preB, [&](int slot) {
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-          if ((e * NSLOT) / NE == slot && !(args.dbg & 4)) gate(zv, hw, e / 16, e % 16);
+          if ((e * NSLOT) / NE == slot) gate(zv, hw, e / 16, e % 16);
       });
       loadB(WREC, brec0);                        // first recurrent weights of step s+1, ahead of the barrier
     } else {
@@ -425,6 +424,269 @@ lstm_layer_kernel(const LstmArgs args) {
   // last step's h
   copyout_read(hbuf + (T & 1) * HBUF);
   copyout_write(dir ? 0 : T - 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Split-bf16 variant of the Bi-LSTM layer kernel.
+// Every f32 operand x is written as hi + mid + lo with three bf16 terms (24 mantissa bits, i.e. the
+// whole f32 value) and the product a*b is formed from the six term pairs with i + j <= 2,
+//     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid,
+// each on v_mfma_f32_32x32x16_bf16 with f32 accumulation: the dropped pairs are below 2^-24 of the
+// product, so the result is as accurate as the f32 pipe (tools/bf16_split_study.py: max |dp| vs
+// fp64 equal to the f32 path, no argmax flips) at 6/16 of its matrix time.  Weights are split on
+// the host (exact); activations are split in registers as they are loaded (the f32 tiled layouts
+// and every other kernel are untouched).  Gates run after the matrix phase (no read-out copy): the
+// register budget goes to R = 2 row tiles per wave, which is what keeps the 1.5x larger operand
+// stream inside the CU's 64 B/clk vector-memory path.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct Split3 { bf16x8 t[3]; };
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) {
+  return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16);
+}
+
+// x[0..7] -> three bf16x8 terms, round-to-nearest-even at every level
+__device__ __forceinline__ Split3 split3(const f32x4& lo4, const f32x4& hi4) {
+  Split3 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = j < 4 ? lo4[j] : hi4[j - 4];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - bf16_to_f32(h);
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - bf16_to_f32(m);
+    o.t[0][j] = h;
+    o.t[1][j] = m;
+    o.t[2][j] = (__bf16)r2;
+  }
+  return o;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct LstmSplitModelParams {
+  const void* wsplit;     // [dir][hg][kb][gate][term 3][64 lanes][8 bf16]; kb: input k-blocks then recurrent
+  const float* bias;      // [dir][hg][gate][32]
+  const float* bn_scale;  // [2H]
+  const float* bn_shift;  // [2H]
+  ActView in0, in1;
+  float* out;             // tiled window-major [tiles][T][2H/4][32][4]
+};
+struct LstmSplitArgs {
+  LstmSplitModelParams m[2];
+  int T;
+  int n_rows;
+};
+
+// grid = (ceil(tiles/(R*WR)), 2, 2), block = 64*NG*WR.  K0 = 4*KQ0, K1 = 4*KQ1, H all multiples of 16.
+template <int KQ0, int KQ1, int H, int R, int WR, int ACT>
+__global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
+lstm_split_kernel(const LstmSplitArgs args) {
+  constexpr int NG = (H + 31) / 32;
+  constexpr int KB0 = KQ0 / 4, KB1 = KQ1 / 4, KB_IN = KB0 + KB1, KB_REC = H / 16, KB = KB_IN + KB_REC;
+  constexpr int ROWS = 32 * R * WR;
+  constexpr int PLANE = ROWS * 4 + 4;
+  constexpr int HBUF = (NG * 32 / 4) * PLANE;
+  constexpr int NTHREADS = 64 * NG * WR;
+  static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
+
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
+  __shared__ __attribute__((aligned(16))) float bnl[2 * H];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hg = wave % NG, wr = wave / NG;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int dir = blockIdx.y;
+  const LstmSplitModelParams& P = args.m[blockIdx.z];
+  const int T = args.T;
+  const int row0 = blockIdx.x * ROWS + wr * (32 * R);
+  const int lrow0 = wr * (32 * R);
+
+  // weights: [kb][gate][term] x 1 KiB, buffer-addressed
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(
+      (const char*)P.wsplit + ((size_t)(dir * NG + hg) * KB) * (4 * 3 * 1024), KB * 4 * 3 * 1024);
+  const unsigned wlane = lane * 16;
+  const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * 32 + l31;
+  const float bias4[4] = {bp[0], bp[32], bp[64], bp[96]};
+  const int u = hg * 32 + l31;
+  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half) * 4;
+
+  for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
+    bnl[i] = i < H ? P.bn_scale[dir * H + i] : P.bn_shift[dir * H + i - H];
+  __syncthreads();
+
+  f32x16 c[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+
+  // Input addressing of one timestep: per row tile a buffer resource and a lane offset per segment.
+  struct ABase {
+    __amdgpu_buffer_rsrc_t r0[R], r1[R];
+    unsigned v0[R], v1[R];
+  };
+  auto mk_base = [&](int t) {
+    ABase ab;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ab.r0[r] = make_rsrc(P.in0.ubase(row0 + r * 32, t), 0xffffffffu);
+      ab.v0[r] = P.in0.voff(row0 + r * 32, t, l31, 0) * 4 + half * 1024;    // chunk kq = 4kb + 2*half
+      if constexpr (KQ1 > 0) {
+        ab.r1[r] = make_rsrc(P.in1.ubase(row0 + r * 32, t), 0xffffffffu);
+        ab.v1[r] = P.in1.voff(row0 + r * 32, t, l31, 0) * 4 + half * 1024;
+      } else {
+        ab.r1[r] = ab.r0[r];
+        ab.v1[r] = 0;
+      }
+    }
+    return ab;
+  };
+  // B terms of k-block kb: 4 gates x 3 terms, 1 KiB each
+  auto loadB = [&](int kb, bf16x8 (&bb)[4][3]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm)
+        bb[g][tm] = __builtin_bit_cast(bf16x8, buf_load16(wrs, wlane, ((kb * 4 + g) * 3 + tm) * 1024));
+  };
+  // raw f32 A chunks (two float4 per k-block and row tile) from input segment 0 / 1
+  auto loadA0 = [&](const ABase& ab, int kb, int r, f32x4 (&a)[2]) {
+    a[0] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048);
+    a[1] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048 + 512);
+  };
+  auto loadA1 = [&](const ABase& ab, int kb, int r, f32x4 (&a)[2]) {
+    a[0] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048);
+    a[1] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048 + 512);
+  };
+
+  // Operand pipeline.  A "unit" is one (k-block, row tile): 24 MFMAs (6 term pairs x 4 gates).
+  // Two k-blocks (2R units) run per loop trip on static ring slots:
+  //   b[slot]     weights of the k-block, loaded one k-block (R units) ahead;
+  //   a[slot][r]  raw f32 activations, loaded two k-blocks ahead;
+  //   S[q & 1]    the three bf16 terms of a unit's activations.  They are produced DURING the previous
+  //               unit: ~40 VALU ops that sched_group_barrier interleaves two per MFMA, in the shadow
+  //               of the matrix pipe (done serially in front of each unit they cost 25 % of it).
+  // A trip is one basic block: where its A refills come from (input segment 0, segment 1, the LDS
+  // image of h_{t-1}, or - in the last trip of a step - blocks 0/1 of the NEXT step, which do not
+  // depend on h_t) is a compile-time parameter and the k loop is cut into one rolled loop per source
+  // (branches between units would also let LLVM sink each split down to its use).  The pipeline thus
+  // runs across timesteps and the matrix pipe restarts warm after the gates.
+  static_assert(KB0 % 2 == 0 && KB1 % 2 == 0 && KB_REC % 2 == 0 && KB0 >= 2, "k-block counts must be even");
+  f32x4 a[2][R][2];
+  bf16x8 b[2][4][3];
+  Split3 S[2];
+  ABase cur = mk_base(dir ? T - 1 : 0);
+  loadB(0, b[0]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) loadA0(cur, 0, r, a[0][r]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) loadA0(cur, 1, r, a[1][r]);
+  S[0] = split3(a[0][0][0], a[0][0][1]);
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? (T - 1 - s) : s;
+    const float* hcur = hbuf + (s & 1) * HBUF;
+    float* hnxt = hbuf + ((s + 1) & 1) * HBUF;
+    const float* hp = hcur + (2 * half) * PLANE + (lrow0 + l31) * 4;
+    // the last step "prefetches" its own inputs again (harmless, keeps the trip branch-free)
+    const ABase nxt = mk_base(s + 1 < T ? (dir ? t - 1 : t + 1) : t);
+
+    f32x16 acc[4][R];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[g][r] = splat16(bias4[g]);
+
+    // SRC: 0 = segment 0, 1 = segment 1, 2 = recurrent (LDS), 3 = next step's blocks 0/1
+    auto trip = [&](auto src_tag, int kb) {
+      constexpr int SRC = decltype(src_tag)::value;
+#pragma unroll
+      for (int q = 0; q < 2 * R; ++q) {
+        const int slot = q / R, r = q % R;
+        const int qn = (q + 1) % (2 * R), slot_n = qn / R, r_n = qn % R;
+        // refill the registers the preceding units have released
+        if (r == 0) loadB(slot == 0 ? kb + 1 : (SRC == 3 ? 0 : kb + 2), b[1 - slot]);
+        const int kbA = kb + slot + 2;
+        if constexpr (SRC == 0) loadA0(cur, kbA, r, a[slot][r]);
+        if constexpr (SRC == 1) loadA1(cur, kbA, r, a[slot][r]);
+        if constexpr (SRC == 2) {
+          const float* qh = hp + (kbA - KB_IN) * 4 * PLANE + r * 128;
+          a[slot][r][0] = *(const f32x4*)(qh);
+          a[slot][r][1] = *(const f32x4*)(qh + PLANE);
+        }
+        if constexpr (SRC == 3) loadA0(nxt, slot, r, a[slot][r]);
+        __builtin_amdgcn_sched_barrier(0);
+        S[(q + 1) & 1] = split3(a[slot_n][r_n][0], a[slot_n][r_n][1]);
+        const Split3& as = S[q & 1];
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[g][r] = mfma_bf16(as.t[PA[pr]], b[slot][g][PB[pr]], acc[g][r]);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two VALU ops of the next unit's split
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const int kb_end = (s == 0) ? KB_IN : KB;            // h_0 = 0: no recurrent blocks on the first step
+    int kb = 0;
+#pragma unroll 1
+    for (; kb + 2 < KB0; kb += 2) trip(std::integral_constant<int, 0>{}, kb);
+    if constexpr (KB1 > 0) {
+#pragma unroll 1
+      for (; kb + 2 < KB_IN; kb += 2) trip(std::integral_constant<int, 1>{}, kb);
+    }
+#pragma unroll 1
+    for (; kb + 2 < kb_end; kb += 2) trip(std::integral_constant<int, 2>{}, kb);
+    trip(std::integral_constant<int, 3>{}, kb);
+    cur = nxt;
+
+    // gates, h_t -> LDS
+    {
+      float* hw = hnxt + hw_off;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const float ig = gate_act<ACT>(acc[0][r][reg]);
+          const float fg = gate_act<ACT>(acc[1][r][reg]);
+          const float gg = tanh_fast(acc[2][r][reg]);
+          const float og = gate_act<ACT>(acc[3][r][reg]);
+          const float cn = __builtin_fmaf(fg, c[r][reg], ig * gg);
+          c[r][reg] = cn;
+          hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = og * tanh_fast(cn);
+          // keep the accumulator read-out local to each group of elements (hipcc otherwise hoists
+          // all 64*R v_accvgpr_read to the top: 128 live VGPRs at R=2 and a 15-minute compile)
+          if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    // h_t (+BatchNorm) -> global
+    {
+      constexpr int KQH = H / 4;
+      constexpr int ITEMS = KQH * ROWS;
+      for (int it = threadIdx.x; it < ITEMS; it += NTHREADS) {
+        const int kq = it / ROWS, rr = it % ROWS;
+        f32x4 v = *(const f32x4*)(hnxt + kq * PLANE + rr * 4);
+        const f32x4 sc = *(const f32x4*)(bnl + kq * 4);
+        const f32x4 sh = *(const f32x4*)(bnl + H + kq * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
+        const int tile = blockIdx.x * (R * WR) + rr / 32;
+        float* dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
+        *(f32x4*)dst = v;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -560,7 +822,6 @@ struct CnnArgs {
   int T;                  // window mode: T; event mode: 1
   int n_rows;             // windows (window mode) or events (event mode)
   int n_tiles;            // 32-event tiles to process (per model)
-  int dbg;                // timing experiments only: 8 = skip conv work, 16 = skip matrix work
 };
 
 constexpr int kCnnMatWaves = 4;
@@ -672,7 +933,7 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
     load_x(blockIdx.x, x);
     for (int i = 0; i <= nloc; ++i) {
       // iteration i builds the image of local tile i (the matrix waves consume tile i-1)
-      if (i < nloc && !(args.dbg & 8)) {
+      if (i < nloc) {
         float xn[11];
         load_x(blockIdx.x + (i + 1) * G, xn);        // next tile's samples: a whole iteration of lead
         float* flat = img + (i & 1) * IMG;
@@ -695,7 +956,7 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
     for (int kg = 0; kg < 25; ++kg) bw[kg] = *(const f32x4*)(P.dpack + ((size_t)ct * 25 + kg) * 256 + lane * 4);
     const float bias = P.dbias[ct * 16 + r16];
     for (int i = 0; i <= nloc; ++i) {
-      if (i > 0 && !(args.dbg & 16)) {
+      if (i > 0) {
         const float* flat = img + ((i - 1) & 1) * IMG;
         const int b = blockIdx.x + (i - 1) * G;
         f32x4 acc0 = {bias, bias, bias, bias}, acc1 = acc0;

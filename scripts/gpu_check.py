@@ -18,7 +18,9 @@ def cmp(tag, got, ref):
     print(f"{tag}: n={len(a1)} max|dp1|={np.abs(p1-q1).max():.3e} max|dp2|={np.abs(p2-q2).max():.3e} "
           f"argmax mism {int((a1!=b1).sum())}/{int((a2!=b2).sum())}", flush=True)
 
-for sp in ("ecoli", "human"):
+for sp, split in (("ecoli", 0), ("human", 0), ("ecoli", 14), ("human", 14)):
+    os.environ["NRV_SPLIT"] = str(split)
+    print("SPLIT", split)
     m1, m2 = load_species(sp)
     T = m1.T
     rd, rt = fixture()
@@ -47,9 +49,9 @@ for T in (13,):
     ds = torch.from_numpy(sig).cuda(); dr = torch.from_numpy(rd_).cuda()
     p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
     a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
-    for cfg, dbg in (("-1,2,0,2", 0), ("-1,2,0,2", 0), ("2,2,0,2", 0)):
+    for cfg, dbg in (("-1,2,0,2", 0), ("-1,2,0,2", 0), ("-1,2,0,2", 4), ("-1,2,0,2", 12), ("-1,2,0,2", 14)):
         os.environ["NRV_GEO"] = cfg
-        os.environ["NRV_DBG"] = str(dbg)
+        os.environ["NRV_SPLIT"] = str(dbg)
         print("DBG", dbg)
         rv2 = Reviser(a, b)
         for it in range(3):
