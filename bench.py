@@ -29,6 +29,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32 matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same table: dense bf16 matrix
+# bf16x3 mode: one f32-exact product = 6 bf16 MFMA products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+# mid*mid), so the ceiling for ALGORITHMIC FLOPs on that pipe is the bf16 dense peak / 6.
+BF16X3_PRODUCTS = 6
 
 # MAC per (window, timestep, model): SURVEY.md 8a
 MAC_CNN = 1200 + 9600 + 25600
@@ -176,11 +180,12 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=15.0):
             "reference_keras_tf": ref}
 
 
-def load_traffic(T, batch):
+def load_traffic(T, batch, precision):
     """HBM bytes per lstm3 launch from the committed PMC pass (profiles/*.json), else None."""
     p = os.path.join(ROOT, "profiles", "r01_pmc_lstm3.json")
     try:
         j = json.load(open(p))
+        j = j.get(precision, j)
         if j.get("T") == T and j.get("batch") == batch:
             return j.get("hbm_bytes_per_launch")
     except Exception:
@@ -196,6 +201,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--window", type=int, default=13, help="events per window (T)")
     ap.add_argument("--species", default="ecoli")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="matrix arithmetic of the three large Bi-LSTM layers (include/nanorev.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-all", action="store_true",
@@ -220,7 +227,7 @@ def main():
     T, B = args.window, args.batch
     m1, m2 = load_species(args.species)
     m1, m2 = m1.with_window(T), m2.with_window(T)
-    rv = Reviser(m1, m2, device=local_rank, batch=B)
+    rv = Reviser(m1, m2, device=local_rank, batch=B, precision=args.precision)
     stream = torch.cuda.current_stream()
     rv.set_stream(stream.cuda_stream)
 
@@ -270,6 +277,8 @@ def main():
                         f"generator), batch={B} windows per GPU per step, model1+model2"
                         + ("; T=13 uses the shipped weights + seeded synthetic (78,16) feature kernel" if T != 11 else ""),
             "species": args.species, "window": T, "batch_windows_per_gpu": B,
+            "precision": args.precision + (" (f32 operands split exactly into 3 bf16 terms, 6 MFMA products, "
+                                           "f32 accumulate)" if args.precision == "bf16x3" else ""),
             "parallelism": f"read/window-sharded x{args.gpus}, no collectives",
             "parity_guard_max_abs_dp": dp,
         },
@@ -282,16 +291,27 @@ def main():
             avg_s = prof[k3][0] / max(prof[k3][1], 1) * 1e-3
             fl = flop_lstm3_launch(T, B, executed=True)
             ach = fl / avg_s / 1e12
+            if args.precision == "bf16x3":
+                peak = PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS
+                peak_note = (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {BF16X3_PRODUCTS} products "
+                             "per f32-exact product; achieved counts ALGORITHMIC flops")
+            else:
+                peak = PEAK_F32_MFMA_TFLOPS
+                peak_note = "dense f32 MFMA peak"
             out["roofline"] = {
-                "kernel": k3, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": load_traffic(T, B),
+                "kernel": k3, "bound": "mfma", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": load_traffic(T, B, args.precision),
                 "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": prof[k3][1],
                 "timing": "hipEvent pairs on the launch stream inside the timed region",
+                "peak_note": peak_note,
+                "executed_tflops": ach * (BF16X3_PRODUCTS if args.precision == "bf16x3" else 1),
+                "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
             }
             whole = flop_per_window(T) * B / (ms_per_step * 1e-3) / 1e12
-            out["roofline_whole_step"] = {"achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": whole / PEAK_F32_MFMA_TFLOPS,
+            out["roofline_whole_step"] = {"achieved": whole, "peak": peak, "unit": "TFLOP/s",
+                                          "frac": whole / peak,
+                                          "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
                                           "flop_per_window": flop_per_window(T)}
             out["kernel_us"] = per_kernel_us
         if args.gpus == 1 and not args.no_cpu_baseline:

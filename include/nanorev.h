@@ -84,6 +84,20 @@ int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d
 int nrv_set_batch(nrv_handle* h, int batch_windows);
 int nrv_get_batch(nrv_handle* h);
 
+/* Matrix arithmetic of the three large Bi-LSTM layers (32->64, 192->128, 256->64; >90 % of the
+ * FLOPs).  Both modes accumulate in f32 and meet the same parity bars (tests/test_gpu_parity.py):
+ *   NRV_PREC_BF16X3 (default)  every f32 operand is split exactly into three bf16 terms and each
+ *                    product formed from the six term pairs that matter on the bf16 matrix pipe;
+ *                    errors vs fp64 are those of the f32 pipe, at ~0.6x its time;
+ *   NRV_PREC_F32     plain f32 matrix instructions.
+ * Everything else (signal branch, first Bi-LSTM, head) is f32 in either mode.  Takes effect from
+ * the next call.  The environment variable NRV_PRECISION=f32|bf16x3 sets the mode a new handle
+ * starts in. */
+#define NRV_PREC_F32 0
+#define NRV_PREC_BF16X3 1
+int nrv_set_precision(nrv_handle* h, int mode);
+int nrv_get_precision(nrv_handle* h);
+
 /* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
 int nrv_set_stream(nrv_handle* h, void* hip_stream);
 int nrv_sync(nrv_handle* h);

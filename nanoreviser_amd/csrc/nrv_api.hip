@@ -238,7 +238,8 @@ struct nrv_handle {
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0};
-  int split = 0;                   // bit l set: layer l (1..3 = lstm2..4) runs the split-bf16 kernel (NRV_SPLIT)
+  int split = 14;                  // bit l set: layer l (1..3 = lstm2..4) runs the split-bf16 kernel
+                                   // (nrv_set_precision: NRV_PREC_BF16X3 = 14, NRV_PREC_F32 = 0)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
@@ -387,8 +388,10 @@ static void launch_lstm(nrv_handle* h, const LstmArgs& a, int tiles, int geo) {
 #define NRV_L(RR, WREQ, ACT)                                                                   \
   {                                                                                            \
     constexpr int WW = (NG * WREQ > 4) ? (4 / NG) : WREQ;                                      \
+    LstmArgs la = a;                                                                           \
+    la.n_blk = (tiles + RR * WW - 1) / (RR * WW);                                              \
     hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, RR, WW, PLAIN, ACT>),                  \
-                       dim3((tiles + RR * WW - 1) / (RR * WW), 2, 2), dim3(64 * NG * WW), 0, h->stream, a); \
+                       dim3(lstm_grid(la.n_blk)), dim3(64 * NG * WW), 0, h->stream, la);       \
   }
 #define NRV_G(ACT)                                                                             \
   switch (geo) {                                                                               \
@@ -411,8 +414,10 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   for (int m = 0; m < 2; ++m)
     sa.m[m] = LstmSplitModelParams{ws[m], a.m[m].bias, a.m[m].bn_scale, a.m[m].bn_shift, a.m[m].in0, a.m[m].in1,
                                    a.m[m].out};
-  dim3 grid((tiles + R * WR - 1) / (R * WR), 2, 2), blk(64 * NG * WR);
-  hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);   // hard_sigmoid only
+  sa.n_blk = (tiles + R * WR - 1) / (R * WR);
+  dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -488,7 +493,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[1], d.all + d.l_b[1], d.all + d.l_s[1], d.all + d.l_h[1],
                                win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
     }
-    if ((h->split & 2) && h->act == 0) {
+    if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
       launch_lstm_split<8, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
@@ -501,7 +506,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[2], d.all + d.l_b[2], d.all + d.l_s[2], d.all + d.l_h[2],
                                win_view(h->X2[m], 32), sv, nullptr, 0, h->X3[m]};
     }
-    if ((h->split & 4) && h->act == 0) {
+    if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
     } else {
@@ -513,7 +518,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[3], d.all + d.l_b[3], d.all + d.l_s[3], d.all + d.l_h[3],
                                win_view(h->X3[m], 64), ActView{}, nullptr, 0, h->X2[m] /* X4 aliases X2 */};
     }
-    if ((h->split & 8) && h->act == 0) {
+    if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
@@ -588,7 +593,11 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   nrv_handle* h = new (std::nothrow) nrv_handle();
   if (!h) { g_create_error = "out of host memory"; return NRV_E_NOMEM; }
   h->device = device; h->T = T; h->act = recurrent_act;
-  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s);
+  if (const char* s = getenv("NRV_PRECISION")) {                       // initial nrv_set_precision mode
+    if (!strcmp(s, "f32")) h->split = 0;
+    else if (!strcmp(s, "bf16x3")) h->split = 14;
+  }
+  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 14;   // tuning knob: per-layer mask
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
     int r[4];
     if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)
@@ -639,6 +648,21 @@ int nrv_set_batch(nrv_handle* h, int batch) {
   return ensure_workspace(h);
 }
 int nrv_get_batch(nrv_handle* h) { return h ? h->batch : NRV_E_INVALID; }
+
+int nrv_set_precision(nrv_handle* h, int mode) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (mode != NRV_PREC_F32 && mode != NRV_PREC_BF16X3) {
+    h->err = "nrv_set_precision: unknown mode";
+    return NRV_E_INVALID;
+  }
+  h->split = mode == NRV_PREC_BF16X3 ? 14 : 0;
+  return NRV_OK;
+}
+int nrv_get_precision(nrv_handle* h) {
+  if (!h) return NRV_E_INVALID;
+  return h->split ? NRV_PREC_BF16X3 : NRV_PREC_F32;
+}
 
 int nrv_set_stream(nrv_handle* h, void* s) {
   int rc = check_handle(h);

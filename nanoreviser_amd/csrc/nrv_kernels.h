@@ -132,16 +132,31 @@ struct LstmModelParams {
   float* out;             // tiled window-major [tiles][T][2H/4][32][4]
 };
 
+// XCD-aware block map for the Bi-LSTM layer kernels (guide T1).  Workgroups are dealt round-robin
+// over the 8 XCDs, so blocks b and b + 8 share an XCD and its 4 MiB L2.  With a (rows, dir, model)
+// grid every XCD streams all four (direction, model) weight sets - 3.8 MB of split-bf16 weights in
+// the 192->128 layer, as much as the whole L2 - next to the activations.  Instead the launch is 1-D
+// and the XCD group g = b % 8 fixes the weight set: (dir, model) = (g>>1 & 1, g>>2), two XCDs per
+// set, each keeping under 1 MB of weights resident.  Row blocks: 2*(b/8) + (g&1); a block past
+// n_blk exits.  Placement is a speed matter only.
+struct LstmBlock { int rowblk, dir, model; };
+__device__ __forceinline__ LstmBlock lstm_block() {
+  const int b = blockIdx.x, g = b & 7;
+  return LstmBlock{((b >> 3) << 1) | (g & 1), (g >> 1) & 1, g >> 2};
+}
+__host__ __device__ constexpr int lstm_grid(int n_blk) { return 8 * ((n_blk + 1) / 2); }
+
 struct LstmArgs {
   LstmModelParams m[2];
   int T;
   int n_rows;             // valid rows (windows)
+  int n_blk;              // row blocks (workgroups per direction and model)
 };
 
 // KQ0/KQ1: input segments in 4-feature chunks (K = 4*KQ, K multiple of 8).  H: hidden units per
 // direction, NG = ceil(H/32) hidden groups.  A wave owns one hidden group (32 units x 4 gates) for
 // R row tiles; a workgroup is NG x WR waves covering 32*R*WR rows.
-// grid = (ceil(tiles/(R*WR)), 2 directions, 2 models), block = 64*NG*WR.
+// grid = lstm_grid(ceil(tiles/(R*WR))) (see lstm_block), block = 64*NG*WR.
 //
 // Schedule of one step s (time index t):
 //     Z  = b + x_t W            (already there: computed during step s-1)
@@ -185,10 +200,12 @@ lstm_layer_kernel(const LstmArgs args) {
   const int wr = wave / NG;
   const int half = lane >> 5;
   const int l31 = lane & 31;
-  const int dir = blockIdx.y;
-  const LstmModelParams& P = args.m[blockIdx.z];
+  const LstmBlock blk = lstm_block();
+  if (blk.rowblk >= args.n_blk) return;
+  const int dir = blk.dir;
+  const LstmModelParams& P = args.m[blk.model];
   const int T = args.T;
-  const int row0 = blockIdx.x * ROWS + wr * (32 * R);     // first row of this wave (uniform)
+  const int row0 = blk.rowblk * ROWS + wr * (32 * R);     // first row of this wave (uniform)
   const int lrow0 = wr * (32 * R);                         // same, block-local
 
   // weights: wave-uniform base (SGPR pair) + per-lane 32-bit offset -> saddr addressing, so the
@@ -240,7 +257,7 @@ lstm_layer_kernel(const LstmArgs args) {
         f32x4 v = cov[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
-        const int tile = blockIdx.x * (R * WR) + rr / 32;
+        const int tile = blk.rowblk * (R * WR) + rr / 32;
         float* dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
         *(f32x4*)dst = v;
       }
@@ -481,9 +498,10 @@ struct LstmSplitArgs {
   LstmSplitModelParams m[2];
   int T;
   int n_rows;
+  int n_blk;
 };
 
-// grid = (ceil(tiles/(R*WR)), 2, 2), block = 64*NG*WR.  K0 = 4*KQ0, K1 = 4*KQ1, H all multiples of 16.
+// grid = lstm_grid(ceil(tiles/(R*WR))), block = 64*NG*WR.  K0 = 4*KQ0, K1 = 4*KQ1, H all multiples of 16.
 template <int KQ0, int KQ1, int H, int R, int WR, int ACT>
 __global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
 lstm_split_kernel(const LstmSplitArgs args) {
@@ -502,10 +520,12 @@ lstm_split_kernel(const LstmSplitArgs args) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hg = wave % NG, wr = wave / NG;
   const int half = lane >> 5, l31 = lane & 31;
-  const int dir = blockIdx.y;
-  const LstmSplitModelParams& P = args.m[blockIdx.z];
+  const LstmBlock blk = lstm_block();
+  if (blk.rowblk >= args.n_blk) return;
+  const int dir = blk.dir;
+  const LstmSplitModelParams& P = args.m[blk.model];
   const int T = args.T;
-  const int row0 = blockIdx.x * ROWS + wr * (32 * R);
+  const int row0 = blk.rowblk * ROWS + wr * (32 * R);
   const int lrow0 = wr * (32 * R);
 
   // weights: [kb][gate][term] x 1 KiB, buffer-addressed
@@ -681,7 +701,7 @@ lstm_split_kernel(const LstmSplitArgs args) {
         const f32x4 sh = *(const f32x4*)(bnl + H + kq * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
-        const int tile = blockIdx.x * (R * WR) + rr / 32;
+        const int tile = blk.rowblk * (R * WR) + rr / 32;
         float* dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
         *(f32x4*)dst = v;
       }

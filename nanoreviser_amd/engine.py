@@ -31,8 +31,10 @@ SYMBOLS = [
     "nrv_create", "nrv_destroy", "nrv_predict", "nrv_predict_read", "nrv_predict_device",
     "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
     "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
-    "nrv_window",
+    "nrv_window", "nrv_set_precision", "nrv_get_precision",
 ]
+
+PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
 class NrvError(RuntimeError):
@@ -93,6 +95,8 @@ def load_library(path: Optional[str] = None):
     lib.nrv_last_error.restype = C.c_char_p
     lib.nrv_backend.argtypes = [vp]
     lib.nrv_window.argtypes = [vp]
+    lib.nrv_set_precision.argtypes = [vp, C.c_int]
+    lib.nrv_get_precision.argtypes = [vp]
     if path is None:
         _lib = lib
     return lib
@@ -119,7 +123,7 @@ class _ModelFacade:
 class Reviser:
     def __init__(self, model1: ModelWeights, model2: ModelWeights, device: int = 0,
                  recurrent_activation: str = "hard_sigmoid", batch: int = 4096,
-                 lib_path: Optional[str] = None):
+                 lib_path: Optional[str] = None, precision: Optional[str] = None):
         if model1.T != model2.T:
             raise ValueError("model1/model2 window lengths differ")
         if recurrent_activation not in ("hard_sigmoid", "sigmoid"):
@@ -138,6 +142,8 @@ class Reviser:
         self.device = int(device)
         if batch != 4096:
             self.set_batch(batch)
+        if precision is not None:
+            self.set_precision(precision)
         self.model1 = _ModelFacade(self, 0)
         self.model2 = _ModelFacade(self, 1)
         self._cache_key = None
@@ -239,6 +245,19 @@ class Reviser:
     @property
     def batch(self) -> int:
         return int(self._lib.nrv_get_batch(self._h))
+
+    def set_precision(self, precision: str):
+        """'bf16x3' (default: exact three-term bf16 split on the bf16 matrix pipe, f32-grade results)
+        or 'f32' (plain f32 matrix instructions) for the three large Bi-LSTM layers."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self._check(self._lib.nrv_set_precision(self._h, PRECISIONS[precision]))
+        self._cache_key = None
+
+    @property
+    def precision(self) -> str:
+        v = int(self._lib.nrv_get_precision(self._h))
+        return {b: a for a, b in PRECISIONS.items()}[v]
 
     def set_stream(self, hip_stream: int):
         self._check(self._lib.nrv_set_stream(self._h, hip_stream or None))

@@ -1,4 +1,4 @@
-"""Dev script: first GPU correctness + timing check (not part of the test-suite)."""
+"""Dev script: GPU correctness + per-kernel timing for both precisions (not part of the test-suite)."""
 import os, sys, time
 import torch
 import numpy as np
@@ -18,59 +18,48 @@ def cmp(tag, got, ref):
     print(f"{tag}: n={len(a1)} max|dp1|={np.abs(p1-q1).max():.3e} max|dp2|={np.abs(p2-q2).max():.3e} "
           f"argmax mism {int((a1!=b1).sum())}/{int((a2!=b2).sum())}", flush=True)
 
-for sp, split in (("ecoli", 0), ("human", 0), ("ecoli", 14), ("human", 14)):
-    os.environ["NRV_SPLIT"] = str(split)
-    print("SPLIT", split)
+PRECS = sys.argv[1:] or ["f32", "bf16x3"]
+for sp in ("ecoli", "human"):
     m1, m2 = load_species(sp)
     T = m1.T
     rd, rt = fixture()
     sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, T)
     n = 700
     sw, fw = np.ascontiguousarray(sw[:n]), np.ascontiguousarray(fw[:n])
-    rv = Reviser(m1, m2)
-    got = rv.predict_pair(sw, fw)
     ref64 = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float64)
-    ref32 = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float32)
-    cmp(f"{sp} windows vs f64", got, ref64)
-    cmp(f"{sp} windows vs f32", got, ref32)
-    cmp(f"{sp} oracle f32 vs f64", ref32, ref64)
-    got_r = rv.predict_read(rt.sig_ev[:n + T], rt.feat_ev[:n + T])
-    cmp(f"{sp} read-mode vs f64", got_r, ref64)
-    cmp(f"{sp} read-mode vs window-mode", got_r, got)
-    rv.close()
+    for act in ("hard_sigmoid", "sigmoid"):
+        if act == "sigmoid":
+            ref64 = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float64, recurrent_act="sigmoid")
+        for prec in PRECS:
+            rv = Reviser(m1, m2, precision=prec, recurrent_activation=act)
+            got = rv.predict_pair(sw, fw)
+            cmp(f"{sp} {act} {prec} windows vs f64", got, ref64)
+            got_r = rv.predict_read(rt.sig_ev[:n + T], rt.feat_ev[:n + T])
+            cmp(f"{sp} {act} {prec} read-mode vs window-mode", got_r, got)
+            rv.close()
 
 # timing at T=13 synthetic, batch 4096
-import torch
 m1, m2 = load_species("ecoli")
-for T in (13,):
-    a, b = m1.with_window(T), m2.with_window(T)
-    rv = Reviser(a, b)
-    sig, rd_ = O.synth_windows(4096, T)
-    ds = torch.from_numpy(sig).cuda(); dr = torch.from_numpy(rd_).cuda()
-    p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
-    a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
-    for cfg, dbg in (("-1,2,0,2", 0), ("-1,2,0,2", 0), ("-1,2,0,2", 4), ("-1,2,0,2", 12), ("-1,2,0,2", 14)):
-        os.environ["NRV_GEO"] = cfg
-        os.environ["NRV_SPLIT"] = str(dbg)
-        print("DBG", dbg)
-        rv2 = Reviser(a, b)
-        for it in range(3):
-            rv2.predict_device(ds.data_ptr(), dr.data_ptr(), 4096, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
-        rv2.sync()
-        rv2.prof_enable(True)
-        t0 = time.time()
-        K = 20
-        for it in range(K):
-            rv2.predict_device(ds.data_ptr(), dr.data_ptr(), 4096, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
-        rv2.sync()
-        dt = (time.time() - t0) / K
-        prof = rv2.prof_read()
-        print(f"T={T} GEO={cfg}: {dt*1e3:.3f} ms/batch -> {4096/dt/1e6:.3f} M windows/s", flush=True)
-        for k, (ms, c) in prof.items():
-            print(f"    {k:40s} {ms/max(c,1)*1e3:9.1f} us")
-        rv2.close()
-    if T == 11:
-        got = rv.predict_pair(sig[:512], rd_[:512])
-        ref = O.predict_pair(m1.tensors, m2.tensors, sig[:512], rd_[:512], np.float64)
-        cmp("synthetic T=11 vs f64", got, ref)
-    rv.close()
+T = 13
+a, b = m1.with_window(T), m2.with_window(T)
+sig, rd_ = O.synth_windows(4096, T)
+ds = torch.from_numpy(sig).cuda(); dr = torch.from_numpy(rd_).cuda()
+p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
+a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
+for prec in PRECS + PRECS:
+    rv2 = Reviser(a, b, precision=prec)
+    for it in range(3):
+        rv2.predict_device(ds.data_ptr(), dr.data_ptr(), 4096, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
+    rv2.sync()
+    rv2.prof_enable(True)
+    t0 = time.time()
+    K = 20
+    for it in range(K):
+        rv2.predict_device(ds.data_ptr(), dr.data_ptr(), 4096, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())
+    rv2.sync()
+    dt = (time.time() - t0) / K
+    prof = rv2.prof_read()
+    print(f"T={T} {prec}: {dt*1e3:.3f} ms/batch -> {4096/dt/1e6:.3f} M windows/s", flush=True)
+    for k, (ms, c) in prof.items():
+        print(f"    {k:40s} {ms/max(c,1)*1e3:9.1f} us")
+    rv2.close()

@@ -30,14 +30,28 @@ def assert_argmax(a, p_ref64, tol, what=""):
     return len(bad)
 
 
+@pytest.fixture(scope="module", params=["bf16x3", "f32"], autouse=True)
+def precision(request):
+    """Every test of this module runs once per matrix-arithmetic mode (include/nanorev.h
+    nrv_set_precision); NRV_PRECISION is what a new handle starts in.  Same bars for both."""
+    import os
+    old = os.environ.get("NRV_PRECISION")
+    os.environ["NRV_PRECISION"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("NRV_PRECISION", None)
+    else:
+        os.environ["NRV_PRECISION"] = old
+
+
 @pytest.fixture(scope="module")
-def engines(species_models):
+def engines(species_models, precision):
     import torch
     assert torch.cuda.is_available(), "gpu tests need an MI355X"
     from nanoreviser_amd.engine import Reviser
     revs = {sp: Reviser(*species_models[sp]) for sp in species_models}
     for rv in revs.values():
-        assert rv.backend == "hip"
+        assert rv.backend == "hip" and rv.precision == precision
     yield revs
     for rv in revs.values():
         rv.close()

@@ -36,9 +36,31 @@ def split(x, n):
     return parts
 
 
+def split_f16(x, n, ftz=False):
+    """n f16 terms (11-bit significands); ftz=True zeroes f16 subnormals (what a flushing pipe would do)."""
+    parts, rem = [], np.asarray(x, np.float32)
+    for _ in range(n):
+        p = rem.astype(np.float16).astype(np.float32)
+        if ftz:
+            p = np.where(np.abs(p) < 2.0 ** -14, np.float32(0), p)
+        parts.append(p)
+        rem = (rem - p).astype(np.float32)
+    return parts
+
+
 def make_matmul(mode):
     if mode == "f32":
         return lambda a, b: a @ b
+    if mode in ("h3", "h4", "h3z"):
+        pairs = [(0, 0), (0, 1), (1, 0)] + ([(1, 1)] if mode == "h4" else [])
+
+        def mmh(a, b):
+            A, B = split_f16(a, 2, mode == "h3z"), split_f16(b, 2, mode == "h3z")
+            out = np.zeros((a.shape[0], b.shape[1]), np.float32)
+            for i, j in sorted(pairs, key=lambda p: -(p[0] + p[1])):
+                out = out + (A[i] @ B[j])
+            return out
+        return mmh
     nterm = 2 if mode == "x3" else 3
     pairs = [(i, j) for i in range(nterm) for j in range(nterm) if i + j <= nterm - 1]
 
@@ -100,7 +122,7 @@ def main():
             sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, 11)
             idx = mg[f"{key}/idx"][:256]
             sw, fw = np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx])
-            for mode in ("f32", "x3", "x6"):
+            for mode in (sys.argv[1:] or ("f32", "x3", "x6", "h3", "h4", "h3z")):
                 mm = make_matmul(mode)
                 res = []
                 for m, nm in ((m1, "p1"), (m2, "p2")):
