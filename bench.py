@@ -299,7 +299,8 @@ def main():
                 peak = PEAK_F32_MFMA_TFLOPS
                 peak_note = "dense f32 MFMA peak"
             out["roofline"] = {
-                "kernel": k3, "bound": "mfma", "achieved": ach, "peak": peak,
+                "kernel": ("lstm_split_kernel<32,16,128,2,1> " if args.precision == "bf16x3"
+                           else "lstm_layer_kernel<32,16,128,1,1> ") + f"({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": load_traffic(T, B, args.precision),
                 "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": prof[k3][1],

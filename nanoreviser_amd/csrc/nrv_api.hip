@@ -145,6 +145,46 @@ NRV_HOST_COLD static void pack_lstm_split(const Blob& b, int base, int Kin, int 
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
+// head_mlp_split_kernel: the three per-timestep dense layers as A operands of the transposed
+// product, 126 fragments [64 lanes][8 bf16] (x3 terms): lane l, element j of a fragment hold
+// W[f][n] with n = 32*mt + (l&31) and f the input feature that the B operand carries in slot
+// (h = l>>5, j):  dense1 (B from the tiled input)            f = 16*kb + 8*h + j
+//                 dense2 / main_out (B = accumulator regs)   reg = 8*(kb&1) + j,
+//                                                            f = 32*(kb>>1) + (reg&3) + 8*(reg>>2) + 4*h
+NRV_HOST_COLD static void pack_head_split(const Blob& b, std::vector<float>& out, std::vector<float>& bias) {
+  std::vector<uint16_t> w((size_t)126 * 512, 0);
+  auto emit = [&](int fragbase, float v, int lane, int j) {
+    float rem = v;
+    for (int tm = 0; tm < 3; ++tm) {
+      const uint16_t q = f32_to_bf16_rne(rem);
+      rem -= bf16_to_f32_host(q);
+      w[((size_t)(fragbase + tm) * 64 + lane) * 8 + j] = q;
+    }
+  };
+  const float *W1 = b.t(50), *W2 = b.t(52), *W3 = b.t(54);
+  for (int lane = 0; lane < 64; ++lane)
+    for (int j = 0; j < 8; ++j) {
+      const int h = lane >> 5, n = lane & 31;
+      for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < 8; ++kb)
+          emit((mt * 8 + kb) * 3, W1[(size_t)(16 * kb + 8 * h + j) * 128 + mt * 32 + n], lane, j);
+      for (int kb = 0; kb < 8; ++kb) {
+        const int reg = 8 * (kb & 1) + j, f = 32 * (kb >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        emit(96 + kb * 3, W2[(size_t)f * 32 + n], lane, j);
+      }
+      for (int kb = 0; kb < 2; ++kb) {
+        const int reg = 8 * kb + j, f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        emit(120 + kb * 3, n < 6 ? W3[(size_t)f * 6 + n] : 0.f, lane, j);
+      }
+    }
+  out.assign(w.size() / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+  bias.assign(192, 0.f);
+  memcpy(bias.data(), b.t(51), 128 * 4);
+  memcpy(bias.data() + 128, b.t(53), 32 * 4);
+  memcpy(bias.data() + 160, b.t(55), 6 * 4);
+}
+
 // lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
 //   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
 //   recurrent step s (0..3): U[unit = 4*(lane>>4) + s][g*16 + (lane&15)]  (lane quarter q holds the
@@ -219,6 +259,7 @@ struct DevModel {
   size_t l1w16, l1b16;        // lstm1 packed for the 16x16x4 kernel
   size_t l_ws[4];             // lstm2..4 weights split into three bf16 terms (index 1..3)
   size_t d1p, d1b, d2p, d2b, mop, mob, fw, fb, ow, ob;
+  size_t h_ws, h_wb;          // head_mlp_split_kernel: split weights / biases
   int C;
 };
 
@@ -238,8 +279,8 @@ struct nrv_handle {
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0};
-  int split = 14;                  // bit l set: layer l (1..3 = lstm2..4) runs the split-bf16 kernel
-                                   // (nrv_set_precision: NRV_PREC_BF16X3 = 14, NRV_PREC_F32 = 0)
+  int split = 30;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers) runs its
+                                   // split-bf16 kernel (nrv_set_precision: NRV_PREC_BF16X3 = 30, NRV_PREC_F32 = 0)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
@@ -317,6 +358,9 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     memcpy(mb, b.t(55), 6 * 4);
     d.mob = put(mb, 32);
   }
+  pack_head_split(b, wp, bs);
+  d.h_ws = put(wp.data(), wp.size());
+  d.h_wb = put(bs.data(), bs.size());
   d.fw = put(b.t(56), (size_t)6 * T * 16);
   d.fb = put(b.t(57), 16);
   d.ow = put(b.t(58), (size_t)16 * C);
@@ -538,7 +582,18 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                d.all + d.mop, d.all + d.mob, d.all + d.fw, d.all + d.fb,
                                d.all + d.ow, d.all + d.ob, h->X2[m], h->MO[m], dp[m], da[m], d.C};
     }
-    hipLaunchKernelGGL(head_mlp_kernel, dim3(tiles * T, 2), dim3(64), 0, h->stream, a);
+    if (h->split & 16) {
+      HeadSplitArgs sa;
+      sa.n_units = tiles * T;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        sa.m[m] = HeadSplitModelParams{d.all + d.h_ws, d.all + d.h_wb, h->X2[m], h->MO[m]};
+      }
+      const int blocks = sa.n_units < 512 ? (sa.n_units + 3) / 4 : 128;    // persistent: one per CU and model
+      hipLaunchKernelGGL(head_mlp_split_kernel, dim3(blocks, 2), dim3(256), 0, h->stream, sa);
+    } else {
+      hipLaunchKernelGGL(head_mlp_kernel, dim3(tiles * T, 2), dim3(64), 0, h->stream, a);
+    }
     hipLaunchKernelGGL(head_final_kernel, dim3(tiles, 2), dim3(256), 0, h->stream, a);
     if ((rc = mark(6))) return rc;
   }
@@ -595,9 +650,9 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   h->device = device; h->T = T; h->act = recurrent_act;
   if (const char* s = getenv("NRV_PRECISION")) {                       // initial nrv_set_precision mode
     if (!strcmp(s, "f32")) h->split = 0;
-    else if (!strcmp(s, "bf16x3")) h->split = 14;
+    else if (!strcmp(s, "bf16x3")) h->split = 30;
   }
-  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 14;   // tuning knob: per-layer mask
+  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 30;   // tuning knob: per-layer mask
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
     int r[4];
     if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)
@@ -656,7 +711,7 @@ int nrv_set_precision(nrv_handle* h, int mode) {
     h->err = "nrv_set_precision: unknown mode";
     return NRV_E_INVALID;
   }
-  h->split = mode == NRV_PREC_BF16X3 ? 14 : 0;
+  h->split = mode == NRV_PREC_BF16X3 ? 30 : 0;
   return NRV_OK;
 }
 int nrv_get_precision(nrv_handle* h) {
@@ -790,10 +845,10 @@ int nrv_prof_read(nrv_handle* h, double* ms_total, int64_t* launches) {
 }
 
 const char* nrv_kernel_name(int slot) {
-  static const char* names[NRV_N_KERNELS] = {"cnn_kernel", "lstm1_kernel 6->16",
-                                             "lstm_layer_kernel<lstm2 32->64>",
-                                             "lstm_layer_kernel<lstm3 192->128>",
-                                             "lstm_layer_kernel<lstm4 256->64>", "head_mlp_kernel+head_final_kernel"};
+  // slots are pipeline stages; which kernel runs a stage depends on nrv_set_precision
+  // (lstm_split_kernel / head_mlp_split_kernel for bf16x3, lstm_layer_kernel / head_mlp_kernel for f32)
+  static const char* names[NRV_N_KERNELS] = {"cnn_kernel", "lstm1_kernel 6->16", "lstm2 32->64", "lstm3 192->128",
+                                             "lstm4 256->64", "head_mlp+head_final"};
   return (slot >= 0 && slot < NRV_N_KERNELS) ? names[slot] : "";
 }
 

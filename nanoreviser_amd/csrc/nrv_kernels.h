@@ -1128,6 +1128,149 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
   }
 }
 
+// Stage 1, bf16x3 form (nrv_set_precision): the same three layers on v_mfma_f32_32x32x16_bf16 with
+// the exact three-term split of lstm_split_kernel, computed TRANSPOSED so that the chain never leaves
+// the registers:  Out^T[n][row] = sum_k W[k][n] * X[row][k]  makes the weights the A operand and the
+// activations the B operand (lane = data row), and the C layout of one layer - lane (row, half h)
+// holds features (reg&3) + 8*(reg>>2) + 4h - is, eight registers at a time, exactly a B operand of
+// the next layer once the host packs that layer's weights in the same permuted k order.  No LDS
+// image, no barrier in the loop.  The split weights of all three layers (126 KB) are staged once per
+// workgroup in LDS and shared by its four waves; a wave walks over (row tile, timestep) units.
+// grid = (min(units, 128), 2 models), block = 256.
+struct HeadSplitModelParams {
+  const void* wsplit;     // [126 fragments][64 lanes][8 bf16]: dense1 [mt 4][kb 8][term 3], dense2 [kb 8][term 3], main_out [kb 2][term 3]
+  const float* bias;      // [128 | 32 | 32] (main_out padded with zeros)
+  const float* in;        // LSTM4 output, tiled window-major KQ=32
+  float* mo;              // main_out scratch [unit][32 rows][8]
+};
+struct HeadSplitArgs {
+  HeadSplitModelParams m[2];
+  int n_units;            // tiles * T
+};
+
+__global__ void __launch_bounds__(256) head_mlp_split_kernel(const HeadSplitArgs args) {
+  constexpr int NFRAG = 126;
+  __shared__ __attribute__((aligned(16))) unsigned short wl[NFRAG * 512];
+  __shared__ __attribute__((aligned(16))) float bl[192];
+  const HeadSplitModelParams& P = args.m[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    // 126 KB, 8 x 16 B in flight per thread (a plain copy loop waits out every load)
+    const __amdgpu_buffer_rsrc_t srs = make_rsrc(P.wsplit, NFRAG * 1024);
+    for (int base = 0; base < NFRAG * 64; base += 8 * 256) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = buf_load16(srs, (unsigned)(base + j * 256 + tid) * 16, 0);   // out of range -> 0
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (base + j * 256 + tid < NFRAG * 64) ((f32x4*)wl)[base + j * 256 + tid] = v[j];
+    }
+  }
+  if (tid < 192) bl[tid] = P.bias[tid];
+  __syncthreads();
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // (weight term, activation term)
+  auto frag = [&](int f) __attribute__((always_inline)) {
+    return *(const bf16x8*)(wl + f * 512 + lane * 8);
+  };
+  auto bias_tile = [&](int off) __attribute__((always_inline)) {       // C-layout bias of 32 features at off
+    f32x16 z;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *(const f32x4*)(bl + off + 8 * q + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[4 * q + j] = v[j];
+    }
+    return z;
+  };
+  auto relu8 = [&](const f32x16& z, int base, f32x4& lo, f32x4& hi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo[j] = __builtin_fmaxf(z[base + j], 0.f);
+      hi[j] = __builtin_fmaxf(z[base + 4 + j], 0.f);
+    }
+  };
+  const unsigned av = l31 * 16 + half * 1024;
+  auto load_x = [&](int u, f32x4 (&x)[8][2]) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(P.in + (size_t)u * 32 * 128, 32 * 128 * 4);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      x[kb][0] = buf_load16(ars, av, kb * 2048);
+      x[kb][1] = buf_load16(ars, av, kb * 2048 + 512);
+    }
+  };
+
+  const int stride = gridDim.x * 4;
+  int u = blockIdx.x * 4 + wave;
+  if (u >= args.n_units) return;
+  f32x4 x[8][2];
+  load_x(u, x);
+  for (; u < args.n_units; u += stride) {
+    // dense1: 128 -> 128 (four 32-feature tiles)
+    f32x16 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = bias_tile(mt * 32);
+    Split3 S[2];
+    S[0] = split3(x[0][0], x[0][1]);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      bf16x8 w[4][3];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) w[mt][tm] = frag((mt * 8 + kb) * 3 + tm);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb + 1 < 8) S[(kb + 1) & 1] = split3(x[kb + 1][0], x[kb + 1][1]);
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(w[mt][PA[pr]], S[kb & 1].t[PB[pr]], acc[mt]);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next unit's inputs travel while the two small layers run
+    const int un = u + stride;
+    if (un < args.n_units) load_x(un, x);
+    // dense2: 128 -> 32; k-block kb takes registers 8*(kb&1).. of tile kb>>1 (two accumulators: the
+    // 48 products would otherwise form one dependent chain)
+    f32x16 a2[2];
+    a2[0] = bias_tile(128);
+    a2[1] = splat16(0.f);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      f32x4 lo, hi;
+      relu8(acc[kb >> 1], (kb & 1) * 8, lo, hi);
+      const Split3 s2 = split3(lo, hi);
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+        a2[kb & 1] = mfma_bf16(frag(96 + kb * 3 + PA[pr]), s2.t[PB[pr]], a2[kb & 1]);
+    }
+    f32x16 h2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h2[i] = a2[0][i] + a2[1][i];
+    // main_out: 32 -> 6 (padded to 32)
+    f32x16 a3 = bias_tile(160);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 lo, hi;
+      relu8(h2, kb * 8, lo, hi);
+      const Split3 s3 = split3(lo, hi);
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) a3 = mfma_bf16(frag(120 + kb * 3 + PA[pr]), s3.t[PB[pr]], a3);
+    }
+    // lane (row, half h) holds output features 4h..4h+3 in registers 0..3
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaxf(a3[j], 0.f);
+    *(f32x4*)(P.mo + ((size_t)u * 32 + l31) * 8 + 4 * half) = o;
+  }
+}
+
 // Stage 2: Flatten(6T) -> Dense(16,relu) -> Dense(C,softmax) -> argmax, one row tile per workgroup.
 // 96T+96 MAC per window: VALU, operands as 16-byte LDS reads.  grid = (tiles, 2), block = 256.
 __global__ void __launch_bounds__(256) head_final_kernel(const HeadArgs args) {

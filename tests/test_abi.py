@@ -72,7 +72,7 @@ def test_create_argument_errors(lib):
     assert b"model1" in lib.nrv_last_error(None)
     assert not h.value
     assert lib.nrv_backend(None) == 1
-    assert lib.nrv_kernel_name(3).startswith(b"lstm_layer_kernel<lstm3")
+    assert lib.nrv_kernel_name(3).startswith(b"lstm3")
     lib.nrv_destroy(None)            # no-op
 
 
