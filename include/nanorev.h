@@ -69,6 +69,28 @@ int nrv_predict(nrv_handle* h, const float* signal, const float* read, int64_t n
 int nrv_predict_read(nrv_handle* h, const float* sig_ev, const float* feat_ev, int64_t N,
                      float* p1, float* p2, int8_t* a1, int8_t* a2);
 
+/* Whole reads from RAW samples: the signal segmentation of preprocessing.py:103-131 (per base the
+ * 50 samples around its first sample, (x - shift)/scale, zero padded) runs on the device, so a read
+ * crosses PCIe as int16 samples + int32 event starts + the 6 event features (~46 B per base instead
+ * of 224).  Several reads can share one call: `raw` and the per-event arrays are the reads'
+ * arrays concatenated, `reads[r]` says where read r lies in them and carries its shift / scale
+ * (medians over the read, NanoReviser.py:120 -> preprocessing.py:99-100, computed by the caller).
+ *   raw [n_raw] int16; starts [N] int32, relative to the first sample of their own read;
+ *   feat_ev [N][6] f32.  Outputs: N - T rows, exactly those of nrv_predict_read on the
+ *   concatenated per-event arrays (windows that straddle two reads are the caller's to skip). */
+typedef struct {
+  int64_t raw_off, raw_len;   /* samples of the read inside `raw` */
+  int64_t ev_off, ev_len;     /* events of the read inside the per-event arrays */
+  double shift, scale;
+} nrv_read_desc;
+int nrv_predict_reads_raw(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts,
+                          const float* feat_ev, int64_t N, const nrv_read_desc* reads, int n_reads,
+                          float* p1, float* p2, int8_t* a1, int8_t* a2);
+/* The segmentation alone: sig_ev [N][50] f32 to HOST memory (what nrv_predict_reads_raw feeds the
+ * signal branch; bit-identical to the host stage - used by the parity tests). */
+int nrv_segment_reads(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts, int64_t N,
+                      const nrv_read_desc* reads, int n_reads, float* sig_ev);
+
 /* Same two calls with DEVICE pointers, enqueued on the handle's stream without a host sync
  * (call nrv_sync, or synchronise the stream you passed to nrv_set_stream).  The inputs must be
  * complete in stream order.  The handle's own stream is a blocking stream, i.e. it is ordered

@@ -112,20 +112,31 @@ def parse_read(path: str, group: str, subgroup: str):
     return rd, fq
 
 
-def phred_chars(p1: np.ndarray, p2: np.ndarray) -> np.ndarray:
-    conf = np.minimum(p1.max(-1), p2.max(-1)).astype(np.float64)
+def phred_chars(p1: np.ndarray, p2: np.ndarray, a1=None, a2=None) -> np.ndarray:
+    """Per-window quality from the smaller of the two models' top probabilities.  With the argmax
+    arrays the top probability is a gather (p.max(-1) over a 6-wide axis is 10x slower in NumPy)."""
+    if a1 is not None and a2 is not None and len(a1) == len(p1):
+        idx = np.arange(len(a1))
+        conf = np.minimum(p1[idx, a1], p2[idx, a2]).astype(np.float64)
+    else:
+        conf = np.minimum(p1.max(-1), p2.max(-1)).astype(np.float64)
     q = np.clip(np.round(-10.0 * np.log10(np.maximum(1.0 - conf, 1e-4))), 1, 40).astype(np.int64)
     return (q + 33).astype(np.uint8)
 
 
-def _finish_read(T: int, rt: hs.ReadTensors, p1, p2, a1, a2):
-    """Calls of one read -> (revised sequence, per-base quality string)."""
+def _finish_read(T: int, rt, p1, p2, a1, a2, want_qual: bool = True):
+    """Calls of one read -> (revised sequence, per-base quality string or None)."""
     codes = np.frombuffer(np.asarray(rt.bases, dtype="S1").tobytes(), dtype=np.uint8)
     off, n = (T - 1) // 2, len(a1)
     if n == 0:
         return codes.tobytes().decode("ascii"), "#" * len(codes)
     first, second, count = hs.merge_calls(codes[off:off + n], a1, a2)
-    qc = phred_chars(p1, p2)
+    if not want_qual:                                # FASTA output: no quality string to build
+        z = np.zeros(n, np.uint8)
+        seq_mid, _ = hs.expand_calls(first, second, count, z, z)
+        seq = codes[:off].tobytes() + seq_mid.tobytes() + codes[off + n:].tobytes()
+        return seq.decode("ascii"), None
+    qc = phred_chars(p1, p2, a1, a2)
     seq_mid, q_mid = hs.expand_calls(first, second, count, qc, qc)
     edge = np.full(1, ord("#"), np.uint8)
     seq = codes[:off].tobytes() + seq_mid.tobytes() + codes[off + n:].tobytes()
@@ -133,30 +144,47 @@ def _finish_read(T: int, rt: hs.ReadTensors, p1, p2, a1, a2):
     return seq.decode("ascii"), qual.decode("ascii")
 
 
-def revise_one(reviser, rt: hs.ReadTensors):
-    """One read through the engine -> (revised sequence, per-base quality string)."""
-    p1, p2, a1, a2 = reviser.predict_read(rt.sig_ev, rt.feat_ev)
-    return _finish_read(reviser.T, rt, p1, p2, a1, a2)
+def predict_one(reviser, rt):
+    """Device side of one read -> (p1, p2, a1, a2) over its N-T windows."""
+    if isinstance(rt, hs.RawReadTensors):
+        return reviser.predict_reads_raw([rt.raw], [rt.starts], [rt.feat_ev], [rt.shift], [rt.scale])
+    return reviser.predict_read(rt.sig_ev, rt.feat_ev)
 
 
-def revise_many(reviser, rts: Sequence[hs.ReadTensors]):
+def predict_many(reviser, rts):
     """Several reads in ONE device call: their per-event arrays are concatenated, the engine forms
     every sliding window of the concatenation, and the T windows that straddle each read boundary
-    are simply not used (0.2 % extra work; full launch groups, one host<->device round trip)."""
+    are simply not used (0.2 % extra work; full launch groups, one host<->device round trip).
+    Returns one (p1, p2, a1, a2) per read."""
     if len(rts) == 1:
-        return [revise_one(reviser, rts[0])]
+        return [predict_one(reviser, rts[0])]
     T = reviser.T
-    sig = np.concatenate([rt.sig_ev for rt in rts])
-    feat = np.concatenate([rt.feat_ev for rt in rts])
-    p1, p2, a1, a2 = reviser.predict_read(sig, feat)
+    if all(isinstance(rt, hs.RawReadTensors) for rt in rts):
+        # raw samples + event starts cross PCIe; the (N,50) windows are cut on the device
+        p1, p2, a1, a2 = reviser.predict_reads_raw([rt.raw for rt in rts], [rt.starts for rt in rts],
+                                                   [rt.feat_ev for rt in rts], [rt.shift for rt in rts],
+                                                   [rt.scale for rt in rts])
+    else:
+        sig = np.concatenate([rt.sig_ev for rt in rts])
+        feat = np.concatenate([rt.feat_ev for rt in rts])
+        p1, p2, a1, a2 = reviser.predict_read(sig, feat)
     out, e0 = [], 0
     for rt in rts:
         N = len(rt.feat_ev)
         n = max(N - T, 0)
         sl = slice(e0, e0 + n)                     # window i of the read == window e0+i of the batch
-        out.append(_finish_read(T, rt, p1[sl], p2[sl], a1[sl], a2[sl]))
+        out.append((p1[sl], p2[sl], a1[sl], a2[sl]))
         e0 += N
     return out
+
+
+def revise_one(reviser, rt, want_qual: bool = True):
+    """One read through the engine -> (revised sequence, per-base quality string)."""
+    return _finish_read(reviser.T, rt, *predict_one(reviser, rt), want_qual=want_qual)
+
+
+def revise_many(reviser, rts, want_qual: bool = True):
+    return [_finish_read(reviser.T, rt, *c, want_qual=want_qual) for rt, c in zip(rts, predict_many(reviser, rts))]
 
 
 def _load_one(job):
@@ -168,9 +196,11 @@ def _load_one(job):
     except Exception as e:                           # broken file: nothing to fall back to
         return fn, None, None, repr(e), time.perf_counter() - t0
     try:
-        rt = hs.read_tensors(rd)
+        # int16 samples + starts + features (46 B/base through the pipe and over PCIe); the signal
+        # windows are cut on the device.  Non-int16 signals (never seen in fast5) take the host path.
+        rt = hs.read_tensors_raw(rd) if np.asarray(rd.signal).dtype == np.int16 else hs.read_tensors(rd)
         return fn, rt, fq, None, time.perf_counter() - t0
-    except Exception as e:                           # segmentation failed: originals can still be written
+    except Exception as e:                           # host stage failed: originals can still be written
         return fn, hs.ReadTensors(None, None, rd.bases, 0.0, 0.0), fq, repr(e), time.perf_counter() - t0
 
 
@@ -222,26 +252,18 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         except Exception as e2:
             log(f"[！！！Error] stroring : {fn.split('.')[0]}_out.{args.output_format}...... {e2}")
 
-    def run_batch(batch):
-        """Engine thread: one device call for the batch, then merge + write per read."""
-        t0 = time.perf_counter()
-        try:
-            outs = revise_many(reviser, [rt for _, rt, _ in batch])
-        except Exception:
-            outs = []
-            for fn, rt, fq in batch:                 # isolate the failing read(s)
-                try:
-                    outs.append(revise_one(reviser, rt))
-                except Exception as e:
-                    outs.append(e)
-        stats["engine_s"] += time.perf_counter() - t0
-        for (fn, rt, fq), o in zip(batch, outs):
-            if isinstance(o, Exception):
-                fallback(fn, rt, fq, o)
+    want_qual = args.output_format == "fastq"
+
+    def finish_batch(batch, calls):
+        """Finisher thread: merge + write per read (NumPy + file IO; overlaps the next device call)."""
+        for (fn, rt, fq), c in zip(batch, calls):
+            if isinstance(c, Exception):
+                fallback(fn, rt, fq, c)
                 continue
             try:
-                write_read(args, fn, o[0], o[1])
-                stats["bases"] += len(o[0])
+                seq, qual = _finish_read(reviser.T, rt, *c, want_qual=want_qual)
+                write_read(args, fn, seq, qual)
+                stats["bases"] += len(seq)
                 if not args.test_mode:
                     log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved......")
                 else:
@@ -249,13 +271,28 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             except Exception as e:
                 fallback(fn, rt, fq, e)
 
+    def run_batch(batch):
+        """Engine thread: one device call for the batch; merging and writing go to the finisher."""
+        t0 = time.perf_counter()
+        try:
+            calls = predict_many(reviser, [rt for _, rt, _ in batch])
+        except Exception:
+            calls = []
+            for fn, rt, fq in batch:                 # isolate the failing read(s)
+                try:
+                    calls.append(predict_one(reviser, rt))
+                except Exception as e:
+                    calls.append(e)
+        stats["engine_s"] += time.perf_counter() - t0
+        return fin.submit(finish_batch, batch, calls)
+
     # reads are grouped into device calls of >= kBatchEvents events; the engine runs in its own
     # thread (the C-ABI call releases the GIL) so unpickling the next reads overlaps the device
     kBatchEvents = 8 * max(int(getattr(args, "batch", 4096)), 1024)
     from concurrent.futures import ThreadPoolExecutor
     from collections import deque
     inflight = deque()
-    with ThreadPoolExecutor(1) as eng:
+    with ThreadPoolExecutor(1) as eng, ThreadPoolExecutor(1) as fin:
         batch, nev = [], 0
         for fn, rt, fq, err, dt in results():
             stats["host_s"] += dt
@@ -273,11 +310,11 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                 inflight.append(eng.submit(run_batch, batch))
                 batch, nev = [], 0
                 while len(inflight) > 2:
-                    inflight.popleft().result()
+                    inflight.popleft().result().result()
         if batch:
             inflight.append(eng.submit(run_batch, batch))
         while inflight:
-            inflight.popleft().result()
+            inflight.popleft().result().result()
     return stats
 
 

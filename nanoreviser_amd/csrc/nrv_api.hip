@@ -279,6 +279,12 @@ struct nrv_handle {
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0};
+  // raw-read entry points: samples, event starts and read descriptors of the current call
+  int16_t* d_raw = nullptr;
+  int32_t* d_starts = nullptr;
+  SegRead* d_reads = nullptr;
+  size_t cap_raw = 0, cap_starts = 0, cap_reads = 0;
+  hipEvent_t ev_raw = nullptr;
   int split = 30;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers) runs its
                                    // split-bf16 kernel (nrv_set_precision: NRV_PREC_BF16X3 = 30, NRV_PREC_F32 = 0)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
@@ -690,6 +696,8 @@ void nrv_destroy(nrv_handle* h) {
     if (h->ev_in[st]) (void)hipEventDestroy(h->ev_in[st]);
     if (h->ev_done[st]) (void)hipEventDestroy(h->ev_done[st]);
   }
+  (void)hipFree(h->d_raw); (void)hipFree(h->d_starts); (void)hipFree(h->d_reads);
+  if (h->ev_raw) (void)hipEventDestroy(h->ev_raw);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -767,11 +775,65 @@ int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d
   return NRV_OK;
 }
 
+// ---- raw-read path: upload samples / starts / descriptors once per call, cut windows per group ----
+static int upload_raw(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts, int64_t N,
+                      const nrv_read_desc* reads, int n_reads) {
+  if (n_raw < 0 || N < 0 || n_reads < 0 || (n_raw > 0 && !raw) || (N > 0 && (!starts || !reads || n_reads == 0))) {
+    h->err = "nrv raw reads: bad arguments";
+    return NRV_E_INVALID;
+  }
+  int64_t ev = 0;
+  for (int r = 0; r < n_reads; ++r) {          // descriptors must tile [0, N) in order and stay inside raw
+    const nrv_read_desc& d = reads[r];
+    if (d.ev_off != ev || d.ev_len < 0 || d.raw_off < 0 || d.raw_len < 0 || d.raw_off + d.raw_len > n_raw) {
+      h->err = "nrv raw reads: read descriptors do not tile the event range / exceed the sample array";
+      return NRV_E_INVALID;
+    }
+    ev += d.ev_len;
+  }
+  if (ev != N) { h->err = "nrv raw reads: read descriptors do not cover N events"; return NRV_E_INVALID; }
+  static_assert(sizeof(SegRead) == sizeof(nrv_read_desc), "descriptor layouts must match");
+  auto grow = [&](void** p, size_t* cap, size_t need) -> int {
+    if (need <= *cap) return NRV_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t c = need + need / 2 + 4096;
+    HIPCHK(h, hipMalloc(p, c));
+    *cap = c;
+    return NRV_OK;
+  };
+  int rc;
+  if ((rc = grow((void**)&h->d_raw, &h->cap_raw, (size_t)n_raw * 2)) ||
+      (rc = grow((void**)&h->d_starts, &h->cap_starts, (size_t)N * 4)) ||
+      (rc = grow((void**)&h->d_reads, &h->cap_reads, (size_t)n_reads * sizeof(SegRead))))
+    return rc;
+  if (!h->ev_raw) HIPCHK(h, hipEventCreateWithFlags(&h->ev_raw, hipEventDisableTiming));
+  // the previous call's kernels may still read these buffers only if the caller did not sync; the
+  // host entry points always end synchronised, so plain stream order on the copy stream is enough
+  if (n_raw) HIPCHK(h, hipMemcpyAsync(h->d_raw, raw, (size_t)n_raw * 2, hipMemcpyHostToDevice, h->copy_stream));
+  if (N) HIPCHK(h, hipMemcpyAsync(h->d_starts, starts, (size_t)N * 4, hipMemcpyHostToDevice, h->copy_stream));
+  if (n_reads) HIPCHK(h, hipMemcpyAsync(h->d_reads, reads, (size_t)n_reads * sizeof(SegRead), hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(h->ev_raw, h->copy_stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_raw, 0));
+  return NRV_OK;
+}
+
+static void launch_segment(nrv_handle* h, int n_reads, int64_t ev0, int n_ev, float* d_out) {
+  if (n_ev <= 0) return;
+  SegArgs a{(const short*)h->d_raw, (const int*)h->d_starts, h->d_reads, n_reads, (long long)ev0, n_ev, d_out};
+  const long long total = (long long)n_ev * 50;
+  hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
+}
+
+// raw != 0: read mode with the per-event signal windows cut on the device from the samples already
+// uploaded by upload_raw() (sig is ignored)
 static int predict_host(nrv_handle* h, const float* sig, const float* feat, int64_t n_in, bool read_mode,
-                        float* p1, float* p2, int8_t* a1, int8_t* a2) {
+                        float* p1, float* p2, int8_t* a1, int8_t* a2, int raw_reads = 0) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (n_in < 0 || (n_in > 0 && (!sig || !feat))) { h->err = "nrv_predict: bad arguments"; return NRV_E_INVALID; }
+  if (n_in < 0 || (n_in > 0 && ((!sig && !raw_reads) || !feat))) { h->err = "nrv_predict: bad arguments"; return NRV_E_INVALID; }
   const int T = h->T;
   const int64_t n = read_mode ? n_in - T : n_in;
   // Pipeline over launch groups with two staging sets.  All copies run on the copy stream:
@@ -793,12 +855,13 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     const int st = (int)(g & 1);
     int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
     size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
-    const float* hs = sig + (read_mode ? s * kSig : s * T * kSig);
+    const float* hs = raw_reads ? nullptr : sig + (read_mode ? s * kSig : s * T * kSig);
     const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
-    HIPCHK(h, hipMemcpyAsync(h->d_sig[st], hs, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
+    if (!raw_reads) HIPCHK(h, hipMemcpyAsync(h->d_sig[st], hs, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipMemcpyAsync(h->d_feat[st], hf, ev * kFeat * 4, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_in[st], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[st], 0));
+    if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[st]);
     rc = run_group(h, h->d_sig[st], h->d_feat[st], nb, read_mode, h->d_p[st][0], h->d_p[st][1],
                    h->d_a[st][0], h->d_a[st][1]);
     if (rc) return rc;
@@ -821,6 +884,31 @@ int nrv_predict(nrv_handle* h, const float* signal, const float* read, int64_t n
 int nrv_predict_read(nrv_handle* h, const float* sig_ev, const float* feat_ev, int64_t N, float* p1,
                      float* p2, int8_t* a1, int8_t* a2) {
   return predict_host(h, sig_ev, feat_ev, N, true, p1, p2, a1, a2);
+}
+
+int nrv_predict_reads_raw(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts,
+                          const float* feat_ev, int64_t N, const nrv_read_desc* reads, int n_reads,
+                          float* p1, float* p2, int8_t* a1, int8_t* a2) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = upload_raw(h, raw, n_raw, starts, N, reads, n_reads))) return rc;
+  return predict_host(h, nullptr, feat_ev, N, true, p1, p2, a1, a2, n_reads);
+}
+
+int nrv_segment_reads(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts, int64_t N,
+                      const nrv_read_desc* reads, int n_reads, float* sig_ev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (N > 0 && !sig_ev) { h->err = "nrv_segment_reads: null output"; return NRV_E_INVALID; }
+  if ((rc = upload_raw(h, raw, n_raw, starts, N, reads, n_reads))) return rc;
+  const int64_t chunk = (int64_t)h->cap_rows * h->T;        // events the staging buffer holds
+  for (int64_t e0 = 0; e0 < N; e0 += chunk) {
+    const int ne = (int)((N - e0 < chunk) ? (N - e0) : chunk);
+    launch_segment(h, n_reads, e0, ne, h->d_sig[0]);
+    HIPCHK(h, hipMemcpyAsync(sig_ev + e0 * kSig, h->d_sig[0], (size_t)ne * kSig * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return NRV_OK;
 }
 
 int nrv_prof_enable(nrv_handle* h, int on) {

@@ -31,7 +31,7 @@ SYMBOLS = [
     "nrv_create", "nrv_destroy", "nrv_predict", "nrv_predict_read", "nrv_predict_device",
     "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
     "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
-    "nrv_window", "nrv_set_precision", "nrv_get_precision",
+    "nrv_window", "nrv_set_precision", "nrv_get_precision", "nrv_predict_reads_raw", "nrv_segment_reads",
 ]
 
 PRECISIONS = {"f32": 0, "bf16x3": 1}
@@ -45,6 +45,11 @@ class NrvError(RuntimeError):
 
 class _Weights(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_float)), ("n_f32", C.c_int64)]
+
+
+class _ReadDesc(C.Structure):
+    _fields_ = [("raw_off", C.c_int64), ("raw_len", C.c_int64), ("ev_off", C.c_int64), ("ev_len", C.c_int64),
+                ("shift", C.c_double), ("scale", C.c_double)]
 
 
 _lib = None
@@ -95,6 +100,9 @@ def load_library(path: Optional[str] = None):
     lib.nrv_last_error.restype = C.c_char_p
     lib.nrv_backend.argtypes = [vp]
     lib.nrv_window.argtypes = [vp]
+    i16p, i32p, rdp = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(_ReadDesc)
+    lib.nrv_predict_reads_raw.argtypes = [vp, i16p, C.c_int64, i32p, fp, C.c_int64, rdp, C.c_int, fp, fp, i8p, i8p]
+    lib.nrv_segment_reads.argtypes = [vp, i16p, C.c_int64, i32p, C.c_int64, rdp, C.c_int, fp]
     lib.nrv_set_precision.argtypes = [vp, C.c_int]
     lib.nrv_get_precision.argtypes = [vp]
     if path is None:
@@ -209,6 +217,55 @@ class Reviser:
             self._h, sig_ev.ctypes.data_as(fp), feat_ev.ctypes.data_as(fp), N,
             p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p)))
         return p1, p2, a1, a2
+
+    # ------------------------------------------------------------------ raw reads (device-side segmentation)
+    @staticmethod
+    def _pack_raw(raws, starts, shifts, scales):
+        """Concatenate per-read int16 samples / int32 starts and build the nrv_read_desc array."""
+        raws = [np.ascontiguousarray(r, dtype=np.int16) for r in raws]
+        starts = [np.ascontiguousarray(s, dtype=np.int32) for s in starts]
+        if not (len(raws) == len(starts) == len(shifts) == len(scales)):
+            raise ValueError("raws / starts / shifts / scales must have one entry per read")
+        descs = (_ReadDesc * max(len(raws), 1))()
+        ro = eo = 0
+        for i, (r, s) in enumerate(zip(raws, starts)):
+            descs[i] = _ReadDesc(ro, r.size, eo, s.size, float(shifts[i]), float(scales[i]))
+            ro += r.size
+            eo += s.size
+        raw = np.concatenate(raws) if raws else np.zeros(0, np.int16)
+        st = np.concatenate(starts) if starts else np.zeros(0, np.int32)
+        return raw, st, descs, len(raws)
+
+    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
+        """Reads given as raw int16 samples (from their first event on), int32 event starts, (N,6)
+        event features and the read's shift / scale; the signal windows are cut on the device.
+        Returns the outputs of `predict_read` on the concatenated per-event arrays (sum(N) - T rows)."""
+        raw, st, descs, nr = self._pack_raw(raws, starts, shifts, scales)
+        feat = _as_f32(np.concatenate([np.asarray(f, np.float32).reshape(-1, 6) for f in feats])
+                       if len(feats) else np.zeros((0, 6), np.float32), (6,))
+        N = feat.shape[0]
+        if st.size != N:
+            raise ValueError("starts / feats length mismatch")
+        n = max(N - self.T, 0)
+        p1 = np.empty((n, 6), np.float32)
+        p2 = np.empty((n, 5), np.float32)
+        a1 = np.empty(n, np.int8)
+        a2 = np.empty(n, np.int8)
+        fp, i8p = C.POINTER(C.c_float), C.POINTER(C.c_int8)
+        self._check(self._lib.nrv_predict_reads_raw(
+            self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), raw.size, st.ctypes.data_as(C.POINTER(C.c_int32)),
+            feat.ctypes.data_as(fp), N, descs, nr,
+            p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p)))
+        return p1, p2, a1, a2
+
+    def segment_reads(self, raws, starts, shifts, scales):
+        """The device-side signal segmentation alone: (sum(N), 50) float32."""
+        raw, st, descs, nr = self._pack_raw(raws, starts, shifts, scales)
+        out = np.empty((st.size, 50), np.float32)
+        self._check(self._lib.nrv_segment_reads(
+            self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), raw.size, st.ctypes.data_as(C.POINTER(C.c_int32)),
+            st.size, descs, nr, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     @staticmethod
     def _fingerprint(a):

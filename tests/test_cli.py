@@ -37,6 +37,15 @@ class EchoEngine:
         p2 = np.eye(5, dtype=np.float32)[a1 - 1] * 0.9 + 0.1 / 5
         return p1, p2, a1, (a1 - 1).astype(np.int8)
 
+    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
+        """What the CLI's workers hand over (engine.Reviser.predict_reads_raw): cut the windows with
+        the host stage here and go through the same echo."""
+        from nanoreviser_amd import hoststage as hs
+        for r, s in zip(raws, starts):
+            assert r.dtype == np.int16 and s.dtype == np.int32
+        sig = np.concatenate([hs.segment_windows_f32(r, s, sh, sc) for r, s, sh, sc in zip(raws, starts, shifts, scales)])
+        return self.predict_read(sig, np.concatenate(feats))
+
 
 def test_flag_surface_matches_reference():
     # NanoReviser.py:42-95

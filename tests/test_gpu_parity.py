@@ -315,3 +315,62 @@ def test_set_batch_grows_workspace_and_multiple_handles(species_models):
         assert np.array_equal(x, y) and np.array_equal(x, z)
     rv_small.close(); rv_big.close()
     rv_small.close()                              # idempotent
+
+
+def test_device_segmentation_is_bit_exact_and_raw_reads_match(engines, reads):
+    """SURVEY 8f-1 on the device: the signal windows cut by segment_kernel from int16 samples +
+    event starts are BIT-identical to the host stage (itself pinned to the reference's
+    signal_segmentation by sha256, tests/test_hoststage_golden.py), for every fixture read alone and
+    for all five in one call; predictions through nrv_predict_reads_raw are identical to
+    nrv_predict_read on the host-cut windows, including the windows straddling two reads."""
+    rv = engines["ecoli"]
+    raws = []
+    for key in reads.keys:
+        g, rd, rt = reads(key)
+        rr = hs.read_tensors_raw(rd)
+        assert rr.raw.dtype == np.int16 and rr.starts.dtype == np.int32
+        assert np.array_equal(rr.feat_ev, rt.feat_ev) and rr.shift == rt.shift and rr.scale == rt.scale
+        sig = rv.segment_reads([rr.raw], [rr.starts], [rr.shift], [rr.scale])
+        assert sig.dtype == np.float32 and sig.shape == rt.sig_ev.shape
+        assert np.array_equal(sig.view(np.uint32), rt.sig_ev.view(np.uint32)), key
+        raws.append((rr, rt))
+    # one call, five reads: per-read shift/scale and clipping at each read's own ends
+    sig_all = rv.segment_reads([r.raw for r, _ in raws], [r.starts for r, _ in raws],
+                               [r.shift for r, _ in raws], [r.scale for r, _ in raws])
+    host_all = np.concatenate([t.sig_ev for _, t in raws])
+    assert np.array_equal(sig_all.view(np.uint32), host_all.view(np.uint32))
+    feat_all = np.concatenate([t.feat_ev for _, t in raws])
+    want = rv.predict_read(host_all, feat_all)
+    got = rv.predict_reads_raw([r.raw for r, _ in raws], [r.starts for r, _ in raws],
+                               [r.feat_ev for r, _ in raws], [r.shift for r, _ in raws],
+                               [r.scale for r, _ in raws])
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # edges: starts beyond the samples, a one-sample read, an empty call
+    raw = np.arange(-5, 35, dtype=np.int16)
+    st = np.array([0, 3, 20, 39, 60, 200], np.int32)
+    dev = rv.segment_reads([raw], [st], [1.5], [2.25])
+    assert np.array_equal(dev.view(np.uint32), hs.segment_windows_f32(raw, st, 1.5, 2.25).view(np.uint32))
+    one = rv.segment_reads([raw[:1]], [st[:2]], [0.0], [1.0])
+    assert np.array_equal(one.view(np.uint32), hs.segment_windows_f32(raw[:1], st[:2], 0.0, 1.0).view(np.uint32))
+    assert rv.segment_reads([], [], [], []).shape == (0, 50)
+    e = rv.predict_reads_raw([raw], [st[:3]], [np.zeros((3, 6), np.float32)], [0.0], [1.0])
+    assert e[0].shape == (0, 6) and e[2].shape == (0,)                 # N <= T: no windows
+
+
+def test_raw_read_descriptors_are_validated(engines):
+    from nanoreviser_amd.engine import NrvError, _ReadDesc
+    import ctypes as C
+    rv = engines["ecoli"]
+    raw = np.zeros(100, np.int16)
+    st = np.zeros(20, np.int32)
+    out = np.empty((20, 50), np.float32)
+    for bad in (_ReadDesc(0, 101, 0, 20, 0.0, 1.0),      # samples beyond the array
+                _ReadDesc(0, 100, 1, 19, 0.0, 1.0),      # events do not start at 0
+                _ReadDesc(0, 100, 0, 19, 0.0, 1.0)):     # events do not cover N
+        rc = rv._lib.nrv_segment_reads(rv._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), 100,
+                                       st.ctypes.data_as(C.POINTER(C.c_int32)), 20, C.byref(bad), 1,
+                                       out.ctypes.data_as(C.POINTER(C.c_float)))
+        assert rc == -1
+    with pytest.raises(NrvError):
+        rv._check(rc)
