@@ -270,7 +270,8 @@ def main():
     out = {
         "metric": "bases revised/sec (whole node)", "value": value, "unit": "bases/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f32 via 3xbf16 split (f32 accumulate)",
         "data": "synthetic",
         "config": {
             "workload": f"{args.species} weights, synthetic independent {T}-event windows (SURVEY 8d C4 "
