@@ -254,7 +254,7 @@ def main():
         sys.exit(f"bench.py: HIP path disagrees with the oracle (max|dp|={dp:.2e}); refusing to time it")
 
     if not args.no_prof:
-        rv.prof_enable(1 if args.prof_all else 2)
+        rv.prof_enable(1 if args.prof_all else 3)
         rv.prof_read()
     for _ in range(args.warmup):
         step()
@@ -305,7 +305,7 @@ def main():
                 "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": load_traffic(T, B, args.precision),
                 "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": prof[k3][1],
-                "timing": "hipEvent pairs on the launch stream inside the timed region",
+                "timing": "hipEvent pairs on the launch stream inside the timed region" + ("" if args.prof_all else ", every 8th launch bracketed"),
                 "peak_note": peak_note,
                 "executed_tflops": ach * (BF16X3_PRODUCTS if args.precision == "bf16x3" else 1),
                 "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,

@@ -130,7 +130,7 @@ int nrv_sync(nrv_handle* h);
  * since the last read and returns, per kernel slot, total milliseconds and launch count.
  * Slots: 0 cnn, 1 lstm1, 2 lstm2, 3 lstm3, 4 lstm4, 5 head.  on = 1: every kernel (seven event
  * records per group, ~3 % of a 4096-window group); on = 2: only slot 3, the dominant kernel (two
- * records per group). */
+ * records per group, ~12 us of idle pipe); on = 3: slot 3 on every 8th group only. */
 #define NRV_N_KERNELS 6
 int nrv_prof_enable(nrv_handle* h, int on);
 int nrv_prof_read(nrv_handle* h, double* ms_total /*[NRV_N_KERNELS]*/,

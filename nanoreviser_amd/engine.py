@@ -323,7 +323,8 @@ class Reviser:
         self._check(self._lib.nrv_sync(self._h))
 
     def prof_enable(self, on=True):
-        """True/1: every kernel; 2: only the dominant kernel (lstm3); False/0: off."""
+        """True/1: every kernel; 2: only the dominant kernel (lstm3); 3: the same on every 8th launch
+        group; False/0: off."""
         self._check(self._lib.nrv_prof_enable(self._h, int(on)))
 
     def prof_read(self):
