@@ -710,6 +710,288 @@ lstm_split_kernel(const LstmSplitArgs args) {
 }
 
 // ---------------------------------------------------------------------------------------
+// lstm_pair_kernel: lstm_split_kernel with the timesteps taken in PAIRS.
+// The input blocks of steps s and s+1 use the same weights and neither depends on h, so their
+// products are formed together: one weight fetch feeds 2R row tiles (R of each step) and the weight
+// bytes per MFMA halve for the input part of the layer (60 % of the k-blocks of the 192->128 layer,
+// 80 % of 256->64).  tools/microbench/mfma_rate.hip: the L2->L1 operand feed is what holds the
+// bf16 pipe below its register-only rate.  Schedule of a pair (s, s+1):
+//     in(s, s+1) -> X[0..R), X[R..2R)      2R units per k-block
+//     rec(s)     -> X[0..R);   gates(s)   -> h_s   (LDS);  barrier;  h_s -> global
+//     rec(s+1)   -> X[R..2R);  gates(s+1) -> h_s+1 (LDS);  barrier;  h_s+1 -> global
+// An odd last step runs alone (the R-tile forms of the same code).  Units, rings and the
+// software-pipelined operand split are those of lstm_split_kernel; a trip's refill source, tile
+// count and accumulator base are compile-time parameters.
+// ---------------------------------------------------------------------------------------
+template <int KQ0, int KQ1, int H, int R, int WR, int ACT>
+__global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
+lstm_pair_kernel(const LstmSplitArgs args) {
+  constexpr int NG = (H + 31) / 32;
+  constexpr int KB0 = KQ0 / 4, KB1 = KQ1 / 4, KB_IN = KB0 + KB1, KB_REC = H / 16, KB = KB_IN + KB_REC;
+  constexpr int ROWS = 32 * R * WR;
+  constexpr int PLANE = ROWS * 4 + 4;
+  constexpr int HBUF = (NG * 32 / 4) * PLANE;
+  constexpr int NTHREADS = 64 * NG * WR;
+  constexpr int R2 = 2 * R;
+  static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
+  static_assert(KB0 % 2 == 0 && KB1 % 2 == 0 && KB_REC % 2 == 0 && KB0 >= 2 && KB_REC >= 2, "k-block counts must be even");
+
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
+  __shared__ __attribute__((aligned(16))) float bnl[2 * H];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hg = wave % NG, wr = wave / NG;
+  const int half = lane >> 5, l31 = lane & 31;
+  const LstmBlock blk = lstm_block();
+  if (blk.rowblk >= args.n_blk) return;
+  const int dir = blk.dir;
+  const LstmSplitModelParams& P = args.m[blk.model];
+  const int T = args.T;
+  const int row0 = blk.rowblk * ROWS + wr * (32 * R);
+  const int lrow0 = wr * (32 * R);
+
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(
+      (const char*)P.wsplit + ((size_t)(dir * NG + hg) * KB) * (4 * 3 * 1024), KB * 4 * 3 * 1024);
+  const unsigned wlane = lane * 16;
+  const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * 32 + l31;
+  const float bias4[4] = {bp[0], bp[32], bp[64], bp[96]};
+  const int u = hg * 32 + l31;
+  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half) * 4;
+
+  for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
+    bnl[i] = i < H ? P.bn_scale[dir * H + i] : P.bn_shift[dir * H + i - H];
+  __syncthreads();
+
+  f32x16 c[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+
+  // Input addressing: ONE buffer resource per segment for the whole workgroup (anchored at its first
+  // row tile, t = 0); a timestep is a wave-uniform byte offset per row tile (SGPR) + a lane offset.
+  const float* const base0 = P.in0.ubase(blk.rowblk * ROWS, 0);
+  const float* const base1 = KQ1 > 0 ? P.in1.ubase(blk.rowblk * ROWS, 0) : base0;
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(base0, 0xffffffffu);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(base1, 0xffffffffu);
+  struct ABase {
+    unsigned s0[R], s1[R];   // uniform byte offsets
+    unsigned v0[R], v1[R];   // lane byte offsets (chunk kq = 4kb + 2*half)
+  };
+  auto t_of = [&](int s) __attribute__((always_inline)) { return dir ? (T - 1 - s) : s; };
+  auto mk_base = [&](int s) __attribute__((always_inline)) {
+    const int t = t_of(s < T ? s : T - 1);              // steps past the end alias the last one (harmless prefetch)
+    ABase ab;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ab.s0[r] = (unsigned)((P.in0.ubase(row0 + r * 32, t) - base0) * 4);
+      ab.v0[r] = P.in0.voff(row0 + r * 32, t, l31, 0) * 4 + half * 1024;
+      if constexpr (KQ1 > 0) {
+        ab.s1[r] = (unsigned)((P.in1.ubase(row0 + r * 32, t) - base1) * 4);
+        ab.v1[r] = P.in1.voff(row0 + r * 32, t, l31, 0) * 4 + half * 1024;
+      } else {
+        ab.s1[r] = 0;
+        ab.v1[r] = 0;
+      }
+    }
+    return ab;
+  };
+  auto loadB = [&](int kb, bf16x8 (&bb)[4][3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm)
+        bb[g][tm] = __builtin_bit_cast(bf16x8, buf_load16(wrs, wlane, ((kb * 4 + g) * 3 + tm) * 1024));
+  };
+  // raw f32 A chunks of input k-block kb (either segment), row tile r of the step described by ab
+  auto loadAin = [&](const ABase& ab, int kb, int r, f32x4 (&a)[2]) __attribute__((always_inline)) {
+    if (KQ1 == 0 || kb < KB0) {
+      a[0] = buf_load16(rs0, ab.v0[r], ab.s0[r] + kb * 2048);
+      a[1] = buf_load16(rs0, ab.v0[r], ab.s0[r] + kb * 2048 + 512);
+    } else {
+      a[0] = buf_load16(rs1, ab.v1[r], ab.s1[r] + (kb - KB0) * 2048);
+      a[1] = buf_load16(rs1, ab.v1[r], ab.s1[r] + (kb - KB0) * 2048 + 512);
+    }
+  };
+
+  f32x4 a[2][R2][2];
+  bf16x8 b[2][4][3];
+  Split3 S[2];
+  f32x16 acc[4][R2];
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // term pairs, small ones first
+
+  // One trip = two k-blocks (kb, kb+1) x RE row tiles; accumulator tiles T0 .. T0+RE-1.
+  // SRC (where the A registers released by a unit are refilled from, two k-blocks ahead):
+  //   0 input segment 0, 1 input segment 1   (tile rr belongs to step rr / R: bases ba[rr / R])
+  //   2 the LDS image hp (recurrent blocks; tiles rr < R only)
+  //   3 blocks 0/1 of the NEXT input phase (bases ba[0], ba[1]): a unit refills its tile for both steps
+  //   4 nothing (the phase that follows restarts the A ring after a barrier)
+  // nextB: the k-block whose weights the slot-1 unit requests (kb + 2 inside a phase).
+  auto trip = [&](auto re_tag, auto t0_tag, auto src_tag, int kb, const ABase (&ba)[2], const float* hp,
+                  int nextB) __attribute__((always_inline)) {
+    constexpr int RE = decltype(re_tag)::value, T0 = decltype(t0_tag)::value, SRC = decltype(src_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 2 * RE; ++q) {
+      const int slot = q / RE, rr = q % RE;
+      const int qn = (q + 1) % (2 * RE), slot_n = qn / RE, rr_n = qn % RE;
+      if (rr == 0) loadB(slot == 0 ? kb + 1 : nextB, b[1 - slot]);
+      const int kbA = kb + slot + 2;
+      if constexpr (SRC == 0 || SRC == 1) loadAin(ba[rr / R], kbA, rr % R, a[slot][rr]);
+      if constexpr (SRC == 2) {
+        if (rr < R) {
+          const float* qh = hp + (kbA - KB_IN) * 4 * PLANE + rr * 128;
+          a[slot][rr][0] = *(const f32x4*)(qh);
+          a[slot][rr][1] = *(const f32x4*)(qh + PLANE);
+        }
+      }
+      if constexpr (SRC == 3) {
+        static_assert(SRC != 3 || RE == R, "next-input refills come from single-step trips");
+        loadAin(ba[0], slot, rr, a[slot][rr]);
+        loadAin(ba[1], slot, rr, a[slot][R + rr]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      S[(q + 1) & 1] = split3(a[slot_n][rr_n][0], a[slot_n][rr_n][1]);
+      const Split3& as = S[q & 1];
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g][T0 + rr] = mfma_bf16(as.t[PA[pr]], b[slot][g][PB[pr]], acc[g][T0 + rr]);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two VALU ops of the next unit's split
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  using IR = std::integral_constant<int, R>;
+  using IR2 = std::integral_constant<int, R2>;
+
+  // input blocks of one step (RE = R) or of a pair (RE = 2R); the last trip refills from hp (h_{s-1})
+  auto input_phase = [&](auto re_tag, const ABase (&ba)[2], const float* hp) __attribute__((always_inline)) {
+    int kb = 0;
+#pragma unroll 1
+    for (; kb + 2 < KB0; kb += 2) trip(re_tag, I0{}, I0{}, kb, ba, hp, kb + 2);
+    if constexpr (KB1 > 0) {
+#pragma unroll 1
+      for (; kb + 2 < KB_IN; kb += 2) trip(re_tag, I0{}, I1{}, kb, ba, hp, kb + 2);
+    }
+    trip(re_tag, I0{}, I2{}, kb, ba, hp, kb + 2);
+  };
+  // recurrent blocks of one step into tiles T0..; the last trip either hands over to the next input
+  // phase (last_src 3: bases bn) or to a recurrent phase behind a barrier (last_src 4)
+  auto rec_phase = [&](auto t0_tag, auto last_src, const float* hp, const ABase (&bn)[2], int lastB)
+                       __attribute__((always_inline)) {
+    int kb = KB_IN;
+#pragma unroll 1
+    for (; kb + 2 < KB; kb += 2) trip(IR{}, t0_tag, I2{}, kb, bn, hp, kb + 2);
+    trip(IR{}, t0_tag, last_src, kb, bn, hp, lastB);
+  };
+  auto restart_rec = [&](const float* hp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float* qh = hp + sl * 4 * PLANE + r * 128;
+        a[sl][r][0] = *(const f32x4*)(qh);
+        a[sl][r][1] = *(const f32x4*)(qh + PLANE);
+      }
+    S[0] = split3(a[0][0][0], a[0][0][1]);
+  };
+  auto gates = [&](auto t0_tag, float* hw) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0_tag)::value;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float ig = gate_act<ACT>(acc[0][T0 + r][reg]);
+        const float fg = gate_act<ACT>(acc[1][T0 + r][reg]);
+        const float gg = tanh_fast(acc[2][T0 + r][reg]);
+        const float og = gate_act<ACT>(acc[3][T0 + r][reg]);
+        const float cn = __builtin_fmaf(fg, c[r][reg], ig * gg);
+        c[r][reg] = cn;
+        hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = og * tanh_fast(cn);
+        if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the accumulator read-out local
+      }
+  };
+  auto copyout = [&](const float* hsrc, int t) __attribute__((always_inline)) {
+    constexpr int KQH = H / 4;
+    constexpr int ITEMS = KQH * ROWS;
+    for (int it = threadIdx.x; it < ITEMS; it += NTHREADS) {
+      const int kq = it / ROWS, rr = it % ROWS;
+      f32x4 v = *(const f32x4*)(hsrc + kq * PLANE + rr * 4);
+      const f32x4 sc = *(const f32x4*)(bnl + kq * 4);
+      const f32x4 sh = *(const f32x4*)(bnl + H + kq * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
+      const int tile = blk.rowblk * (R * WR) + rr / 32;
+      float* dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
+      *(f32x4*)dst = v;
+    }
+  };
+  auto himg = [&](int s) __attribute__((always_inline)) { return hbuf + ((s + 1) & 1) * HBUF; };   // image of h_s
+  const int hp_off = (2 * half) * PLANE + (lrow0 + l31) * 4;
+
+  // h_{-1} = 0: the recurrent blocks of step 0 run against a zeroed image (8 of 20 k-blocks of one
+  // step in the 192->128 layer) - that keeps the loop body free of first-iteration branches, whose
+  // merges cost more in register moves than the products do
+  for (int i = threadIdx.x; i < HBUF; i += NTHREADS) hbuf[i] = 0.f;          // image of h_{-1} is buffer 0
+  __syncthreads();
+
+  // pipeline prologue: weights of block 0, inputs of blocks 0/1 of the first pair
+  {
+    const ABase b0[2] = {mk_base(0), mk_base(1)};
+    loadB(0, b[0]);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int rr = 0; rr < R2; ++rr) loadAin(b0[rr / R], sl, rr % R, a[sl][rr]);
+    S[0] = split3(a[0][0][0], a[0][0][1]);
+  }
+
+  int s = 0;
+#pragma unroll 1
+  for (; s + 1 < T; s += 2) {
+    const ABase ba[2] = {mk_base(s), mk_base(s + 1)};
+    const ABase bn[2] = {mk_base(s + 2), mk_base(s + 3)};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int rr = 0; rr < R2; ++rr) acc[g][rr] = splat16(bias4[g]);
+    const float* hp0 = himg(s - 1) + hp_off;
+    input_phase(IR2{}, ba, hp0);
+    rec_phase(I0{}, I4{}, hp0, bn, KB_IN);
+    gates(I0{}, himg(s) + hw_off);
+    __syncthreads();
+    copyout(himg(s), t_of(s));
+    const float* hp1 = himg(s) + hp_off;
+    restart_rec(hp1);
+    rec_phase(IR{}, I3{}, hp1, bn, 0);
+    gates(IR{}, himg(s + 1) + hw_off);
+    __syncthreads();
+    copyout(himg(s + 1), t_of(s + 1));
+  }
+  if (s < T) {                                               // odd T: the last step alone
+    const ABase ba[2] = {mk_base(s), mk_base(s)};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[g][r] = splat16(bias4[g]);
+    const float* hp0 = himg(s - 1) + hp_off;
+    input_phase(IR{}, ba, hp0);
+    rec_phase(I0{}, I4{}, hp0, ba, KB_IN);
+    gates(I0{}, himg(s) + hw_off);
+    __syncthreads();
+    copyout(himg(s), t_of(s));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Device-side signal segmentation (preprocessing.py:103-131 through
 // hoststage.segment_windows_f32): per base the 50 samples [st-25, st+25) clipped to the read,
 // (x - shift)/scale in IEEE f64 then rounded to f32, symmetric zero padding (the odd sample goes in
