@@ -469,8 +469,9 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
   // Timestep pairs (lstm_pair_kernel) pay for the layers that run one row tile per wave (32->64,
-  // 256->64: -7 % / -5 %); at R = 2 the second accumulator set leaves too few registers (measured
-  // 336 -> 380 us for 192->128), so that layer keeps lstm_split_kernel.  NRV_PAIR=0 turns pairs off.
+  // 256->64: -7 % / -5 %); at R = 2 the second accumulator set leaves too few registers (192->128
+  // measured 335 -> 362 us even with the cell state moved to LDS: the remaining spill reloads drain
+  // the in-order prefetch queue), so that layer keeps lstm_split_kernel.  NRV_PAIR=0 turns pairs off.
   static const bool pair_ok = !(getenv("NRV_PAIR") && atoi(getenv("NRV_PAIR")) == 0);
   if constexpr (R == 1) {
     if (pair_ok) {

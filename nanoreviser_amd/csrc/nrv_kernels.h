@@ -736,8 +736,13 @@ lstm_pair_kernel(const LstmSplitArgs args) {
   static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
   static_assert(KB0 % 2 == 0 && KB1 % 2 == 0 && KB_REC % 2 == 0 && KB0 >= 2 && KB_REC >= 2, "k-block counts must be even");
 
+  // At R = 2 the two accumulator sets take all 256 AGPRs and c (32 registers) is what pushes the
+  // VGPR side over: every spill reload sits in the in-order vmcnt queue behind the operand prefetches
+  // and drains it.  The cell state then lives in LDS ([cell][thread], conflict-free; 32 KB).
+  constexpr bool CLDS = R >= 2;
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
   __shared__ __attribute__((aligned(16))) float bnl[2 * H];
+  __shared__ float cl[CLDS ? 16 * R * NTHREADS : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -763,9 +768,14 @@ lstm_pair_kernel(const LstmSplitArgs args) {
     bnl[i] = i < H ? P.bn_scale[dir * H + i] : P.bn_shift[dir * H + i - H];
   __syncthreads();
 
-  f32x16 c[R];
+  f32x16 c[CLDS ? 1 : R];
+  if constexpr (CLDS) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+    for (int i = 0; i < 16 * R; ++i) cl[i * NTHREADS + threadIdx.x] = 0.f;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+  }
 
   // Input addressing: ONE buffer resource per segment for the whole workgroup (anchored at its first
   // row tile, t = 0); a timestep is a wave-uniform byte offset per row tile (SGPR) + a lane offset.
@@ -913,8 +923,12 @@ lstm_pair_kernel(const LstmSplitArgs args) {
         const float fg = gate_act<ACT>(acc[1][T0 + r][reg]);
         const float gg = tanh_fast(acc[2][T0 + r][reg]);
         const float og = gate_act<ACT>(acc[3][T0 + r][reg]);
-        const float cn = __builtin_fmaf(fg, c[r][reg], ig * gg);
-        c[r][reg] = cn;
+        float cprev;
+        if constexpr (CLDS) cprev = cl[(r * 16 + reg) * NTHREADS + threadIdx.x];
+        else cprev = c[r][reg];
+        const float cn = __builtin_fmaf(fg, cprev, ig * gg);
+        if constexpr (CLDS) cl[(r * 16 + reg) * NTHREADS + threadIdx.x] = cn;
+        else c[r][reg] = cn;
         hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = og * tanh_fast(cn);
         if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the accumulator read-out local
       }
@@ -957,21 +971,25 @@ lstm_pair_kernel(const LstmSplitArgs args) {
   int s = 0;
 #pragma unroll 1
   for (; s + 1 < T; s += 2) {
-    const ABase ba[2] = {mk_base(s), mk_base(s + 1)};
-    const ABase bn[2] = {mk_base(s + 2), mk_base(s + 3)};
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int rr = 0; rr < R2; ++rr) acc[g][rr] = splat16(bias4[g]);
     const float* hp0 = himg(s - 1) + hp_off;
-    input_phase(IR2{}, ba, hp0);
-    rec_phase(I0{}, I4{}, hp0, bn, KB_IN);
+    {                                                        // (address sets live only where they are used)
+      const ABase ba[2] = {mk_base(s), mk_base(s + 1)};
+      input_phase(IR2{}, ba, hp0);
+      rec_phase(I0{}, I4{}, hp0, ba, KB_IN);
+    }
     gates(I0{}, himg(s) + hw_off);
     __syncthreads();
     copyout(himg(s), t_of(s));
     const float* hp1 = himg(s) + hp_off;
     restart_rec(hp1);
-    rec_phase(IR{}, I3{}, hp1, bn, 0);
+    {
+      const ABase bn[2] = {mk_base(s + 2), mk_base(s + 3)};
+      rec_phase(IR{}, I3{}, hp1, bn, 0);
+    }
     gates(IR{}, himg(s + 1) + hw_off);
     __syncthreads();
     copyout(himg(s + 1), t_of(s + 1));
