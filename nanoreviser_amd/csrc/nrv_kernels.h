@@ -812,9 +812,10 @@ lstm_pair_kernel(const LstmSplitArgs args) {
       for (int tm = 0; tm < 3; ++tm)
         bb[g][tm] = __builtin_bit_cast(bf16x8, buf_load16(wrs, wlane, ((kb * 4 + g) * 3 + tm) * 1024));
   };
-  // raw f32 A chunks of input k-block kb (either segment), row tile r of the step described by ab
-  auto loadAin = [&](const ABase& ab, int kb, int r, f32x4 (&a)[2]) __attribute__((always_inline)) {
-    if (KQ1 == 0 || kb < KB0) {
+  // raw f32 A chunks of input k-block kb, row tile r of the step described by ab.  SEG (0 / 1) is a
+  // compile-time parameter: a run-time segment test inside a trip would split its basic block.
+  auto loadAin = [&](auto seg_tag, const ABase& ab, int kb, int r, f32x4 (&a)[2]) __attribute__((always_inline)) {
+    if constexpr (decltype(seg_tag)::value == 0) {
       a[0] = buf_load16(rs0, ab.v0[r], ab.s0[r] + kb * 2048);
       a[1] = buf_load16(rs0, ab.v0[r], ab.s0[r] + kb * 2048 + 512);
     } else {
@@ -845,7 +846,7 @@ lstm_pair_kernel(const LstmSplitArgs args) {
       const int qn = (q + 1) % (2 * RE), slot_n = qn / RE, rr_n = qn % RE;
       if (rr == 0) loadB(slot == 0 ? kb + 1 : nextB, b[1 - slot]);
       const int kbA = kb + slot + 2;
-      if constexpr (SRC == 0 || SRC == 1) loadAin(ba[rr / R], kbA, rr % R, a[slot][rr]);
+      if constexpr (SRC == 0 || SRC == 1) loadAin(src_tag, ba[rr / R], kbA, rr % R, a[slot][rr]);
       if constexpr (SRC == 2) {
         if (rr < R) {
           const float* qh = hp + (kbA - KB_IN) * 4 * PLANE + rr * 128;
@@ -855,8 +856,8 @@ lstm_pair_kernel(const LstmSplitArgs args) {
       }
       if constexpr (SRC == 3) {
         static_assert(SRC != 3 || RE == R, "next-input refills come from single-step trips");
-        loadAin(ba[0], slot, rr, a[slot][rr]);
-        loadAin(ba[1], slot, rr, a[slot][R + rr]);
+        loadAin(std::integral_constant<int, 0>{}, ba[0], slot, rr, a[slot][rr]);       // blocks 0/1 lie in segment 0
+        loadAin(std::integral_constant<int, 0>{}, ba[1], slot, rr, a[slot][R + rr]);
       }
       __builtin_amdgcn_sched_barrier(0);
       S[(q + 1) & 1] = split3(a[slot_n][rr_n][0], a[slot_n][rr_n][1]);
@@ -964,7 +965,7 @@ lstm_pair_kernel(const LstmSplitArgs args) {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-      for (int rr = 0; rr < R2; ++rr) loadAin(b0[rr / R], sl, rr % R, a[sl][rr]);
+      for (int rr = 0; rr < R2; ++rr) loadAin(std::integral_constant<int, 0>{}, b0[rr / R], sl, rr % R, a[sl][rr]);
     S[0] = split3(a[0][0][0], a[0][0][1]);
   }
 
