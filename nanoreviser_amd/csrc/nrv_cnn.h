@@ -1,0 +1,202 @@
+// Signal branch: conv1d x2 + BN + residual + flatten + dense(400 -> 64).
+#pragma once
+#include "nrv_common.h"
+
+namespace nrv {
+
+// ---------------------------------------------------------------------------------------
+// Signal branch: conv1d(1->8,k3)+ReLU+BN, conv1d(8->8,k3)+ReLU+BN, + signal, flatten(400),
+// dense(400->64).  nanorevcnn.py:17-38, output_handeler.py:209-215.
+//
+// Persistent, wave-specialised workgroups (one per CU): five CONV waves turn the next 32-event tile
+// into its 400-feature A-fragment image in LDS on the VALU (f32 VALU rate == f32 MFMA rate on
+// gfx950, and N=8 would waste 3/4 of a matrix tile) while four MATRIX waves run the 400->64 dense
+// of the previous tile out of the other image buffer, their share of the dense kernel resident in
+// registers; one barrier per tile, no other synchronisation.
+// Measured: conv alone 59 us, dense alone 49 us, together 90 us per 4096-window group - f32 MFMA
+// and f32 VALU work of co-resident waves add up rather than overlap (they price against the same
+// 64 FLOP/clk/SIMD), so what this structure buys is the removed barriers/staging (113 -> 90 us).
+// ---------------------------------------------------------------------------------------
+struct CnnModelParams {
+  const float* conv;      // 24 w1[k][o], 8 b1, 8 s1, 8 h1, 192 w2[k][c][o], 8 b2, 8 s2, 8 h2  (=264)
+  const float* dpack;     // dense 400->64 packed for 16x16x4 MFMA: [ct 4][kg 25][64][4]
+  const float* dbias;     // [64]
+  float* out;             // tiled, KQ=16: window-major [wtile][t][16][32][4] or event-major [etile][16][32][4]
+};
+struct CnnArgs {
+  CnnModelParams m[2];
+  const float* signal;    // [n][T][50] (window mode) or [N][50] (event mode)
+  int T;                  // window mode: T; event mode: 1
+  int n_rows;             // windows (window mode) or events (event mode)
+  int n_tiles;            // 32-event tiles to process (per model)
+};
+
+constexpr int kCnnMatWaves = 4;
+constexpr int kCnnConvWaves = 4;   // 32 events x 8 position chunks (7,7,6,6,6,6,6,6) = 256 threads
+constexpr int kCnnThreads = 64 * (kCnnMatWaves + kCnnConvWaves);
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// conv1+BN -> conv2+BN -> +signal for NP consecutive positions of one event, written into the
+// A-fragment image.  x[] holds samples p0-2 .. p0+NP+1.
+template <int NP>
+__device__ __forceinline__ void conv_positions(const float* __restrict__ cw, const float (&x)[11], int p0,
+                                               int r, float* flat, int plane) {
+  float b1v[NP + 2][8];                            // bn1 at positions p0-1 .. p0+NP
+  {
+    float w1[48];                                  // w1[3][8], b1[8], bn1 scale[8], shift[8]
+#pragma unroll
+    for (int k = 0; k < 48; ++k) w1[k] = cw[k];
+#pragma unroll
+    for (int q = 0; q < NP + 2; ++q) {
+      const int p = p0 - 1 + q;
+      const bool inside = (p >= 0) && (p < kSig);
+      const float xm = x[q], xc = x[q + 1], xp = x[q + 2];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float v = w1[24 + o];
+        v = __builtin_fmaf(xm, w1[0 * 8 + o], v);
+        v = __builtin_fmaf(xc, w1[1 * 8 + o], v);
+        v = __builtin_fmaf(xp, w1[2 * 8 + o], v);
+        v = __builtin_fmaxf(v, 0.f);
+        v = v * w1[32 + o] + w1[40 + o];
+        b1v[q][o] = inside ? v : 0.f;
+      }
+    }
+  }
+  // conv2, weight-stationary: each (tap k, in-channel ci) row of 8 weights is fetched once and
+  // applied to all NP positions of this thread as 4 packed FMAs each.
+  const float* w2 = cw + 48;
+  f32x2 acc[NP][4];
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[q][o] = f32x2{w2[192 + 2 * o], w2[192 + 2 * o + 1]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+      f32x2 wrow[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        wrow[o] = f32x2{w2[(k * 8 + ci) * 8 + 2 * o], w2[(k * 8 + ci) * 8 + 2 * o + 1]};
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const float av = b1v[q + k][ci];
+        const f32x2 a2 = f32x2{av, av};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[q][o] = __builtin_elementwise_fma(a2, wrow[o], acc[q][o]);
+      }
+    }
+  float s2[8], h2[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) { s2[o] = w2[200 + o]; h2[o] = w2[208 + o]; }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const float xc = x[q + 2];
+    float o8[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float v = __builtin_fmaxf(acc[q][o >> 1][o & 1], 0.f);
+      v = v * s2[o] + h2[o];
+      o8[o] = v + xc;                              // Add(): broadcast the raw signal over channels
+    }
+    const int p = p0 + q;                          // flat index p*8+o -> kq = 2p, 2p+1
+    *(f32x4*)(flat + (2 * p) * plane + r * 4) = f32x4{o8[0], o8[1], o8[2], o8[3]};
+    *(f32x4*)(flat + (2 * p + 1) * plane + r * 4) = f32x4{o8[4], o8[5], o8[6], o8[7]};
+  }
+}
+
+__global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
+  constexpr int PLANE = 32 * 4 + 4;         // floats per kq plane of the image (+4: conflict-free)
+  constexpr int IMG = 100 * PLANE;
+  __shared__ __attribute__((aligned(16))) float img[2 * IMG];
+
+  const CnnModelParams& P = args.m[blockIdx.y];
+  const int T = args.T;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int ntile = args.n_tiles, G = gridDim.x;
+  const int nloc = (ntile - (int)blockIdx.x + G - 1) / G;     // tiles of this workgroup: b = blockIdx.x + i*G
+
+  if (wave >= kCnnMatWaves) {
+    // ================================ CONV role ==============================================
+    // wave cw0 holds the two 7-position chunks, the others 6-position chunks (wave-uniform count)
+    const int cwv = wave - kCnnMatWaves;
+    const int chunk = cwv * 2 + (lane >> 5);
+    const int r = lane & 31;
+    const int p0 = chunk < 2 ? 7 * chunk : 14 + 6 * (chunk - 2);
+    float x[11];                                   // samples p0-2 .. p0+8 of the tile being convolved
+    auto load_x = [&](int b, float (&xo)[11]) {
+      const int row = (b / T) * 32 + r, t = b % T;
+      const bool ok = b < ntile && row < args.n_rows;
+      const float* src = args.signal + ((size_t)row * T + t) * kSig;
+#pragma unroll
+      for (int i = 0; i < 11; ++i) {
+        const int p = p0 - 2 + i;
+        xo[i] = (ok && p >= 0 && p < kSig) ? src[p] : 0.f;
+      }
+    };
+    load_x(blockIdx.x, x);
+    for (int i = 0; i <= nloc; ++i) {
+      // iteration i builds the image of local tile i (the matrix waves consume tile i-1)
+      if (i < nloc) {
+        float xn[11];
+        load_x(blockIdx.x + (i + 1) * G, xn);        // next tile's samples: a whole iteration of lead
+        float* flat = img + (i & 1) * IMG;
+        if (cwv == 0) conv_positions<7>(P.conv, x, p0, r, flat, PLANE);
+        else conv_positions<6>(P.conv, x, p0, r, flat, PLANE);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) x[k] = xn[k];
+      }
+      __syncthreads();
+    }
+  } else {
+    // ================================ MATRIX role ============================================
+    // wave w owns 16 output features (column tile w) for all 32 rows (two 16-row accumulators).
+    // Its share of the 400x64 kernel (25 k-groups x 4 VGPRs) stays in registers for the whole
+    // launch, so a tile costs 50 LDS reads + 200 v_mfma_f32_16x16x4_f32 and no weight traffic.
+    const int ct = wave;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    f32x4 bw[25];
+#pragma unroll
+    for (int kg = 0; kg < 25; ++kg) bw[kg] = *(const f32x4*)(P.dpack + ((size_t)ct * 25 + kg) * 256 + lane * 4);
+    const float bias = P.dbias[ct * 16 + r16];
+    for (int i = 0; i <= nloc; ++i) {
+      if (i > 0) {
+        const float* flat = img + ((i - 1) & 1) * IMG;
+        const int b = blockIdx.x + (i - 1) * G;
+        f32x4 acc0 = {bias, bias, bias, bias}, acc1 = acc0;
+        const float* ap = flat + q4 * PLANE + r16 * 4;
+        f32x4 a0[2], a1[2];
+        a0[0] = *(const f32x4*)(ap);
+        a1[0] = *(const f32x4*)(ap + 64);
+#pragma unroll
+        for (int kg = 0; kg < 25; ++kg) {
+          const int cur = kg & 1;
+          if (kg + 1 < 25) {
+            a0[cur ^ 1] = *(const f32x4*)(ap + (kg + 1) * 4 * PLANE);
+            a1[cur ^ 1] = *(const f32x4*)(ap + (kg + 1) * 4 * PLANE + 64);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[cur][j], bw[kg][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[cur][j], bw[kg][j], acc1, 0, 0, 0);
+          }
+        }
+        float* dst = P.out + (size_t)b * 16 * 128;
+        const int u = ct * 16 + r16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = 4 * q4 + reg;
+          dst[(u >> 2) * 128 + row * 4 + (u & 3)] = acc0[reg];
+          dst[(u >> 2) * 128 + (row + 16) * 4 + (u & 3)] = acc1[reg];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
+}  // namespace nrv
