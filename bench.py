@@ -253,6 +253,12 @@ def main():
     if dp > 1e-4 or not (np.array_equal(a1[:64].cpu().numpy(), b1) and np.array_equal(a2[:64].cpu().numpy(), b2)):
         sys.exit(f"bench.py: HIP path disagrees with the oracle (max|dp|={dp:.2e}); refusing to time it")
 
+    # Untimed priming burst.  The first unsynchronised burst of launches of a process pays a one-off
+    # ~35 ms (measured: 60 queued steps take 76-82 ms the first time, 43 ms ever after, whatever the
+    # idle time in between); with a short --warmup it would land inside the timed region.
+    for _ in range(64):
+        step()
+    sync()
     if not args.no_prof:
         rv.prof_enable(1 if args.prof_all else 3)
         rv.prof_read()
