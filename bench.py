@@ -260,7 +260,9 @@ def main():
         step()
     sync()
     if not args.no_prof:
-        rv.prof_enable(1 if args.prof_all else 3)
+        # every 8th launch of the dominant kernel is bracketed; every launch when the run is short
+        prof_mode = 1 if args.prof_all else (3 if args.steps >= 64 else 2)
+        rv.prof_enable(prof_mode)
         rv.prof_read()
     for _ in range(args.warmup):
         step()
@@ -311,7 +313,7 @@ def main():
                 "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": load_traffic(T, B, args.precision),
                 "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": prof[k3][1],
-                "timing": "hipEvent pairs on the launch stream inside the timed region" + ("" if args.prof_all else ", every 8th launch bracketed"),
+                "timing": "hipEvent pairs on the launch stream inside the timed region" + (", every 8th launch bracketed" if prof_mode == 3 else ""),
                 "peak_note": peak_note,
                 "executed_tflops": ach * (BF16X3_PRODUCTS if args.precision == "bf16x3" else 1),
                 "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
