@@ -6,4 +6,4 @@ import sys
 from nanoreviser_amd.cli import main
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(standalone=True))

@@ -141,6 +141,10 @@ const char* nrv_kernel_name(int slot);
  * nrv_create on this thread).  Never NULL. */
 const char* nrv_last_error(nrv_handle* h);
 
+/* Number of HIP devices visible to this process (0 when there is none or the runtime fails): what
+ * the command line shards reads over (NanoReviser.py:214-219 sharded files over Pool workers). */
+int nrv_device_count(void);
+
 /* Always NRV_BACKEND_HIP: the library has no other backend. */
 int nrv_backend(nrv_handle* h);
 

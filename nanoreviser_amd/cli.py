@@ -334,7 +334,10 @@ def _worker(rank: int, world: int, args, files: List[str], q):
         q.put((rank, None, repr(e)))
 
 
-def main(argv: Optional[Sequence[str]] = None, reviser_factory=None) -> int:
+def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone: bool = False) -> int:
+    """standalone=True (the NanoReviser.py entry point): this process is only the command line, so the
+    engine is loaded without importing torch first (~1.5 s of start-up).  Library callers keep the
+    default: engine.load_library imports torch first so that one HIP runtime serves both."""
     args = get_args(argv)
     if args.output_format not in ("fasta", "fastq"):
         print("[！！！Error] output_format must be fasta or fastq", file=sys.stderr)
@@ -347,9 +350,13 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None) -> int:
         rv = reviser_factory(args, 0)
         stats = [process_files(args, names, rv, print)]
     else:
-        import torch
-        import torch.multiprocessing as mp
-        ndev = torch.cuda.device_count()
+        # the command line needs no torch: without it a process starts ~1.5 s sooner.  (engine.py imports
+        # torch first only so that a LATER torch import in the same process finds one HIP runtime.)
+        if standalone and "torch" not in sys.modules:
+            os.environ.setdefault("NRV_NO_TORCH", "1")
+        import multiprocessing as mp
+        from .engine import device_count
+        ndev = device_count()
         if ndev == 0:
             print("[！！！Error] no MI355X / HIP device visible: the reviser has no CPU path", file=sys.stderr)
             return 2
@@ -391,4 +398,4 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(standalone=True))

@@ -958,6 +958,10 @@ const char* nrv_kernel_name(int slot) {
 
 const char* nrv_last_error(nrv_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 int nrv_backend(nrv_handle* h) { (void)h; return NRV_BACKEND_HIP; }
+int nrv_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
 int nrv_window(nrv_handle* h) { return h ? h->T : NRV_E_INVALID; }
 
 }  // extern "C"

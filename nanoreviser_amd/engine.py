@@ -32,6 +32,7 @@ SYMBOLS = [
     "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
     "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
     "nrv_window", "nrv_set_precision", "nrv_get_precision", "nrv_predict_reads_raw", "nrv_segment_reads",
+    "nrv_device_count",
 ]
 
 PRECISIONS = {"f32": 0, "bf16x3": 1}
@@ -100,6 +101,7 @@ def load_library(path: Optional[str] = None):
     lib.nrv_last_error.restype = C.c_char_p
     lib.nrv_backend.argtypes = [vp]
     lib.nrv_window.argtypes = [vp]
+    lib.nrv_device_count.argtypes = []
     i16p, i32p, rdp = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(_ReadDesc)
     lib.nrv_predict_reads_raw.argtypes = [vp, i16p, C.c_int64, i32p, fp, C.c_int64, rdp, C.c_int, fp, fp, i8p, i8p]
     lib.nrv_segment_reads.argtypes = [vp, i16p, C.c_int64, i32p, C.c_int64, rdp, C.c_int, fp]
@@ -108,6 +110,11 @@ def load_library(path: Optional[str] = None):
     if path is None:
         _lib = lib
     return lib
+
+
+def device_count() -> int:
+    """HIP devices visible to this process, asked of the engine library itself (no torch needed)."""
+    return int(load_library().nrv_device_count())
 
 
 def _as_f32(a, shape_tail):
