@@ -185,6 +185,25 @@ NRV_HOST_COLD static void pack_head_split(const Blob& b, std::vector<float>& out
   memcpy(bias.data() + 160, b.t(55), 6 * 4);
 }
 
+// cnn_kernel<true>: dense 400->64 as split-bf16 B fragments [kb 25][nh 2][term 3][64 lanes][8 bf16];
+// lane l, element j hold W[k][n] with k = 16*kb + 8*(l>>5) + j (flatten index p*8+o), n = 32*nh + (l&31).
+NRV_HOST_COLD static void pack_cnn_split(const float* W, std::vector<float>& out) {
+  std::vector<uint16_t> w((size_t)25 * 2 * 3 * 512, 0);
+  for (int kb = 0; kb < 25; ++kb)
+    for (int nh = 0; nh < 2; ++nh)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          float rem = W[(size_t)(16 * kb + 8 * (lane >> 5) + j) * 64 + 32 * nh + (lane & 31)];
+          for (int tm = 0; tm < 3; ++tm) {
+            const uint16_t q = f32_to_bf16_rne(rem);
+            rem -= bf16_to_f32_host(q);
+            w[((size_t)((kb * 2 + nh) * 3 + tm) * 64 + lane) * 8 + j] = q;
+          }
+        }
+  out.assign(w.size() / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+}
+
 // lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
 //   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
 //   recurrent step s (0..3): U[unit = 4*(lane>>4) + s][g*16 + (lane&15)]  (lane quarter q holds the
@@ -254,7 +273,7 @@ struct DevModel {
   float* all = nullptr;       // one allocation holding every packed tensor of the model
   size_t n = 0;
   // offsets (floats) into `all`
-  size_t conv, dpack, dbias;
+  size_t conv, dpack, dbias, dsplit;
   size_t l_w[4], l_b[4], l_s[4], l_h[4];
   size_t l1w16, l1b16;        // lstm1 packed for the 16x16x4 kernel
   size_t l_ws[4];             // lstm2..4 weights split into three bf16 terms (index 1..3)
@@ -285,8 +304,8 @@ struct nrv_handle {
   SegRead* d_reads = nullptr;
   size_t cap_raw = 0, cap_starts = 0, cap_reads = 0;
   hipEvent_t ev_raw = nullptr;
-  int split = 30;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers) runs its
-                                   // split-bf16 kernel (nrv_set_precision: NRV_PREC_BF16X3 = 30, NRV_PREC_F32 = 0)
+  int split = 62;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers, 5 = signal-branch
+                                   // dense) runs its split-bf16 kernel (nrv_set_precision: BF16X3 = 62, F32 = 0)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
   std::string err;
   // profiling
@@ -336,6 +355,8 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
   pack_dense16(b.t(32), 400, 64, wp);
   d.dpack = put(wp.data(), wp.size());
   d.dbias = put(b.t(33), 64);
+  pack_cnn_split(b.t(32), wp);
+  d.dsplit = put(wp.data(), wp.size());
   const int lbase[4] = {12, 22, 34, 44}, lK[4] = {6, 32, 192, 256}, lH[4] = {16, 64, 128, 64};
   const int bnbase[4] = {18, 28, 40, -1};
   for (int l = 0; l < 4; ++l) {
@@ -517,7 +538,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     CnnArgs a;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
-      a.m[m] = CnnModelParams{d.all + d.conv, d.all + d.dpack, d.all + d.dbias, h->S[m]};
+      a.m[m] = CnnModelParams{d.all + d.conv, d.all + d.dpack, d.all + d.dbias, d.all + d.dsplit, h->S[m]};
     }
     a.signal = d_sig;
     if (read_mode) { a.T = 1; a.n_rows = n + T - 1; }
@@ -525,7 +546,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     a.n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
     // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
     int blocks = a.n_tiles < 128 ? a.n_tiles : 128;
-    hipLaunchKernelGGL(cnn_kernel, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+    if (h->split & 32) hipLaunchKernelGGL(cnn_kernel<true>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+    else hipLaunchKernelGGL(cnn_kernel<false>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     if ((rc = mark(1))) return rc;
   }
   auto win_view = [&](const float* p, int kq) { return ActView{p, kq, 0, T, 1}; };
@@ -671,9 +693,9 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   h->device = device; h->T = T; h->act = recurrent_act;
   if (const char* s = getenv("NRV_PRECISION")) {                       // initial nrv_set_precision mode
     if (!strcmp(s, "f32")) h->split = 0;
-    else if (!strcmp(s, "bf16x3")) h->split = 30;
+    else if (!strcmp(s, "bf16x3")) h->split = 62;
   }
-  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 30;   // tuning knob: per-layer mask
+  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 62;   // tuning knob: per-layer mask
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
     int r[4];
     if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)
@@ -734,7 +756,7 @@ int nrv_set_precision(nrv_handle* h, int mode) {
     h->err = "nrv_set_precision: unknown mode";
     return NRV_E_INVALID;
   }
-  h->split = mode == NRV_PREC_BF16X3 ? 30 : 0;
+  h->split = mode == NRV_PREC_BF16X3 ? 62 : 0;
   return NRV_OK;
 }
 int nrv_get_precision(nrv_handle* h) {

@@ -1,6 +1,6 @@
 // Signal branch: conv1d x2 + BN + residual + flatten + dense(400 -> 64).
 #pragma once
-#include "nrv_common.h"
+#include "nrv_lstm_bf16x3.h"   // Split3, split3, mfma_bf16
 
 namespace nrv {
 
@@ -21,6 +21,7 @@ struct CnnModelParams {
   const float* conv;      // 24 w1[k][o], 8 b1, 8 s1, 8 h1, 192 w2[k][c][o], 8 b2, 8 s2, 8 h2  (=264)
   const float* dpack;     // dense 400->64 packed for 16x16x4 MFMA: [ct 4][kg 25][64][4]
   const float* dbias;     // [64]
+  const void* dsplit;     // dense 400->64 as split-bf16 B fragments: [kb 25][nh 2][term 3][64 lanes][8 bf16]
   float* out;             // tiled, KQ=16: window-major [wtile][t][16][32][4] or event-major [etile][16][32][4]
 };
 struct CnnArgs {
@@ -107,10 +108,18 @@ __device__ __forceinline__ void conv_positions(const float* __restrict__ cw, con
   }
 }
 
+// SPLIT (bf16x3 mode): the dense layer runs on v_mfma_f32_32x32x16_bf16 with the exact three-term
+// split.  The bf16 pipe overlaps with the conv waves' VALU work where the f32 one adds to it, and
+// the four matrix waves are arranged 2 column halves x 2 K halves so that no activation is split
+// more than twice: wave (nh, kh) holds its 13 (12) k-blocks of split weights in registers, the kh = 1
+// wave hands its partial tile to its partner through a double-buffered 4 KB LDS slab, and the
+// partner adds it one iteration later (behind the tile barrier that exists anyway).
+template <bool SPLIT>
 __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
   constexpr int PLANE = 32 * 4 + 4;         // floats per kq plane of the image (+4: conflict-free)
   constexpr int IMG = 100 * PLANE;
   __shared__ __attribute__((aligned(16))) float img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) float part[SPLIT ? 2 * 2 * 16 * 64 : 4];   // [buf][nh][reg][lane]
 
   const CnnModelParams& P = args.m[blockIdx.y];
   const int T = args.T;
@@ -153,6 +162,66 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
     }
   } else {
     // ================================ MATRIX role ============================================
+    if constexpr (SPLIT) {
+      const int nh = wave & 1, kh = wave >> 1;
+      const int half = lane >> 5, l31 = lane & 31;
+      constexpr int NKB = 13;                                   // k-blocks of 16: kh = 0 takes 0..12, kh = 1 13..24
+      const int kb0 = kh * NKB, nkb = kh ? 12 : 13;
+      bf16x8 bw[NKB][3];
+#pragma unroll
+      for (int k = 0; k < NKB; ++k)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) {
+          const int kb = kb0 + (k < nkb ? k : 0);                 // (the unused 13th block of kh = 1 is never multiplied)
+          bw[k][tm] = *(const bf16x8*)((const char*)P.dsplit + ((size_t)((kb * 2 + nh) * 3 + tm) * 64 + lane) * 16);
+        }
+      const float bias = kh == 0 ? P.dbias[nh * 32 + l31] : 0.f;
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      f32x16 prev = splat16(0.f);                                // kh = 0: finished K-half of the previous tile
+      auto finish = [&](int i_tile) __attribute__((always_inline)) {   // kh = 0: tile i_tile = prev + partner's half
+        const float* ps = part + ((i_tile & 1) * 2 + nh) * 1024 + lane;
+        float* dst = P.out + (size_t)(blockIdx.x + i_tile * G) * 16 * 128;
+        const int u = nh * 32 + l31;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+          dst[(u >> 2) * 128 + row * 4 + (u & 3)] = prev[reg] + ps[reg * 64];
+        }
+      };
+      for (int i = 0; i <= nloc; ++i) {
+        if (kh == 0 && i >= 2) finish(i - 2);
+        if (i > 0) {
+          const float* flat = img + ((i - 1) & 1) * IMG;
+          const float* ap = flat + (4 * kb0 + 2 * half) * PLANE + l31 * 4;
+          f32x16 acc = splat16(bias);
+          f32x4 a[2][2];
+          a[0][0] = *(const f32x4*)(ap);
+          a[0][1] = *(const f32x4*)(ap + PLANE);
+#pragma unroll
+          for (int k = 0; k < NKB; ++k) {
+            if (k < nkb) {                                         // wave-uniform
+              if (k + 1 < NKB) {
+                const int kn = (k + 1 < nkb) ? k + 1 : k;
+                a[(k + 1) & 1][0] = *(const f32x4*)(ap + kn * 4 * PLANE);
+                a[(k + 1) & 1][1] = *(const f32x4*)(ap + kn * 4 * PLANE + PLANE);
+              }
+              const Split3 sa = split3(a[k & 1][0], a[k & 1][1]);
+#pragma unroll
+              for (int pr = 0; pr < 6; ++pr) acc = mfma_bf16(sa.t[PA[pr]], bw[k][PB[pr]], acc);
+            }
+          }
+          if (kh == 0) {
+            prev = acc;
+          } else {
+            float* ps = part + (((i - 1) & 1) * 2 + nh) * 1024 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) ps[reg * 64] = acc[reg];
+          }
+        }
+        __syncthreads();
+      }
+      if (kh == 0 && nloc >= 1) finish(nloc - 1);
+    } else {
     // wave w owns 16 output features (column tile w) for all 32 rows (two 16-row accumulators).
     // Its share of the 400x64 kernel (25 k-groups x 4 VGPRs) stays in registers for the whole
     // launch, so a tile costs 50 LDS reads + 200 v_mfma_f32_16x16x4_f32 and no weight traffic.
@@ -194,6 +263,7 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
         }
       }
       __syncthreads();
+    }
     }
   }
 }
