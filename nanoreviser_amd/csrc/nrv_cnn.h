@@ -136,14 +136,22 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
     const int r = lane & 31;
     const int p0 = chunk < 2 ? 7 * chunk : 14 + 6 * (chunk - 2);
     float x[11];                                   // samples p0-2 .. p0+8 of the tile being convolved
+    // One buffer resource per tile (64-bit base wave-uniform) + one 32-bit lane offset + immediates:
+    // eleven independent loads, no per-sample 64-bit address and no branch.  Out-of-window samples
+    // and rows past the end are clamped to a valid address and masked to zero.  (Per-sample
+    // predicated loads spilled an address pair, and the reload's vmcnt(0) serialised the loads.)
     auto load_x = [&](int b, float (&xo)[11]) {
-      const int row = (b / T) * 32 + r, t = b % T;
-      const bool ok = b < ntile && row < args.n_rows;
-      const float* src = args.signal + ((size_t)row * T + t) * kSig;
+      const int bt = b < ntile ? b : 0;
+      const int wt = bt / T, t = bt % T;
+      const bool ok = b < ntile && wt * 32 + r < args.n_rows;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(args.signal + ((size_t)wt * 32 * T + t) * kSig, 0xffffffffu);
+      const unsigned rowoff = ok ? (unsigned)(r * T * kSig) : 0u;
 #pragma unroll
       for (int i = 0; i < 11; ++i) {
         const int p = p0 - 2 + i;
-        xo[i] = (ok && p >= 0 && p < kSig) ? src[p] : 0.f;
+        const int pc = p < 0 ? 0 : (p > kSig - 1 ? kSig - 1 : p);
+        const float v = buf_load4(rs, (rowoff + (unsigned)pc) * 4, 0);
+        xo[i] = (ok && p >= 0 && p < kSig) ? v : 0.f;
       }
     };
     load_x(blockIdx.x, x);

@@ -38,6 +38,9 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
   i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
   return __builtin_bit_cast(f32x4, v);
 }
+__device__ __forceinline__ float buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
 
 // row of accumulator register `reg` for this lane (C/D map of the 32x32 MFMA)
 __device__ __forceinline__ int acc_row(int reg, int lane) {
