@@ -130,6 +130,9 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
 
   if (wave >= kCnnMatWaves) {
     // ================================ CONV role ==============================================
+    // The conv waves are the critical path of a tile (the matrix waves finish early and wait at the
+    // barrier): they win the VALU arbitration against the matrix wave of their SIMD.
+    __builtin_amdgcn_s_setprio(3);
     // wave cw0 holds the two 7-position chunks, the others 6-position chunks (wave-uniform count)
     const int cwv = wave - kCnnMatWaves;
     const int chunk = cwv * 2 + (lane >> 5);
