@@ -8,7 +8,7 @@ namespace nrv {
 // Signal branch: conv1d(1->8,k3)+ReLU+BN, conv1d(8->8,k3)+ReLU+BN, + signal, flatten(400),
 // dense(400->64).  nanorevcnn.py:17-38, output_handeler.py:209-215.
 //
-// Persistent, wave-specialised workgroups (one per CU): five CONV waves turn the next 32-event tile
+// Persistent, wave-specialised workgroups (one per CU): four CONV waves turn the next 32-event tile
 // into its 400-feature A-fragment image in LDS on the VALU (f32 VALU rate == f32 MFMA rate on
 // gfx950, and N=8 would waste 3/4 of a matrix tile) while four MATRIX waves run the 400->64 dense
 // of the previous tile out of the other image buffer, their share of the dense kernel resident in
