@@ -374,3 +374,29 @@ def test_raw_read_descriptors_are_validated(engines):
         assert rc == -1
     with pytest.raises(NrvError):
         rv._check(rc)
+
+
+def test_random_shapes_vs_f32_oracle(species_models, precision):
+    """Seeded random window lengths (1..32), batch sizes (1..700), launch-group sizes and both
+    recurrent activations against the NumPy f32 oracle (scripts/gpu_fuzz.py runs the open-ended
+    version).  Both sides are f32 paths, so the bound is twice the fp32 noise floor."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    rng = np.random.default_rng(20261)
+    m1, m2 = species_models["ecoli"]
+    for _ in range(10):
+        T = int(rng.integers(1, 33))
+        n = int(rng.integers(1, 700))
+        batch = int(rng.choice([64, 96, 500, 4096]))
+        act = str(rng.choice(["hard_sigmoid", "sigmoid"]))
+        a, b = m1.with_window(T), m2.with_window(T)
+        sig, rd = O.synth_windows(n, T, seed=int(rng.integers(1 << 30)))
+        rv = Reviser(a, b, recurrent_activation=act, batch=batch)
+        assert rv.precision == precision
+        p1, p2, a1, a2 = rv.predict_pair(sig, rd)
+        q1, q2, b1, b2 = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float32, recurrent_act=act)
+        assert np.abs(p1 - q1).max() <= 2e-4 and np.abs(p2 - q2).max() <= 2e-4, (T, n, batch, act)
+        for arr, brr, q in ((a1, b1, q1), (a2, b2, q2)):
+            for i in np.nonzero(arr != brr)[0]:
+                assert q[i, brr[i]] - q[i, arr[i]] <= 2e-4, (T, n, batch, act, int(i))
+        rv.close()
