@@ -3,23 +3,40 @@
 
 A "step" is one pass of the hot path (signal CNN + 4 Bi-LSTM + head, model1 AND model2) over one
 batch of 4096 synthetic independent 13-event windows per GPU (north_star target; generator:
-SURVEY.md 8d C4; E. coli weights + the seeded synthetic (78,16) `feature` kernel, because the
-shipped files are T=11 - SURVEY.md F3).  One window == one revised base.
+SURVEY.md 8d C4 = nanoreviser_amd/workload.py; E. coli weights + the seeded synthetic (78,16)
+`feature` kernel, because the shipped files are T=11 - SURVEY.md F3).  One window == one revised base.
 
   python bench.py --gpus N --steps K --warmup W
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE from the environment), and typed as is - then this process, which
+never touches a GPU, starts the N ranks itself as fresh child processes (the reference fans out from
+one command the same way, NanoReviser.py:203-219), relays rank 0's JSON line and returns the first
+non-zero exit code.
 
 Inputs are resident in HBM before the timed region.  Reads/windows are independent, so ranks own
 disjoint shards and the data path has NO collective (weak scaling); the only communication is the
 barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
 
-The `cpu_baseline` leg (rank 0, N=1 only) times oracle/nrv_oracle.c - the plain-C f32 port, test
-infrastructure - on a bounded sample of the same windows, on the host cores.  It is a reported
-baseline, never the thing measured as `value`.
+Besides the contract keys the line carries (N = 1, rank 0; --no-extras turns them off):
+  roofline            dominant kernel (lstm3), hipEvent pairs on the launch stream INSIDE the timed
+                      region on every 8th launch (a bracket costs ~12 us of idle pipe, so bracketing
+                      every launch would perturb a 20-step run by 2 %)
+  kernel_us           every kernel, from a separate untimed pass after the timed region
+  f32_mode            the same step with plain f32 matrix instructions (roofline 157.3 TFLOP/s)
+  host_inclusive      nrv_predict / nrv_predict_read / nrv_predict_reads_raw from HOST memory
+                      (H2D + D2H inside the timed call) - never `value`
+  read_mode           config C5: one 200 k-event read, human weights, device-formed windows
+  configs             C2 (ecoli, batch 512) and C3 (human, batch 4096) on the replicated fixture reads
+  cpu_baseline        oracle/nrv_oracle.c (plain-C f32 port of the reference graph - test
+                      infrastructure) on the host cores: all cores, one thread, affinity, and the
+                      host stage's us/base.  A reported baseline, never the thing measured as `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,15 +46,20 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32 matrix)
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # same table: dense bf16 matrix
-# bf16x3 mode: one f32-exact product = 6 bf16 MFMA products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
-# mid*mid), so the ceiling for ALGORITHMIC FLOPs on that pipe is the bf16 dense peak / 6.
-BF16X3_PRODUCTS = 6
+PEAK_16BIT_MFMA_TFLOPS = 2500.0     # same table: dense bf16 / f16 matrix
+# f32-grade products on the 16-bit matrix pipe (include/nanorev.h, nrv_set_precision):
+#   bf16x3: f32 operand = 3 bf16 terms, product = 6 MFMA products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid)
+#   f16x2 : scaled f32 operand = 2 f16 terms, product = 3 MFMA products (hi*hi, hi*lo, lo*hi)
+# The ceiling for ALGORITHMIC FLOPs in such a mode is the dense 16-bit peak / products.
+PRODUCTS = {"bf16x3": 6, "f16x2": 3, "f32": 1}
+DTYPE = {"f32": "f32", "bf16x3": "f32 via 3xbf16 split (f32 accumulate)",
+         "f16x2": "f32 via scaled 2xf16 split (f32 accumulate)"}
 
 # MAC per (window, timestep, model): SURVEY.md 8a
 MAC_CNN = 1200 + 9600 + 25600
 MAC_L = {1: 2816, 2: 49152, 3: 327680, 4: 163840}
 MAC_HEAD_T = 16384 + 4096 + 192
+FLOP_PER_BASE_DEDUP = {11: 24973216, 13: 29487264}     # SURVEY.md 8d, read mode (per-event CNN)
 
 
 def flop_per_window(T):
@@ -55,8 +77,20 @@ def flop_lstm3_launch(T, n_windows, executed=True):
     return 2 * mac * 2 * n_windows                       # 2 FLOP/MAC, two models
 
 
+def mode_peak(precision):
+    if precision == "f32":
+        return PEAK_F32_MFMA_TFLOPS, "dense f32 MFMA peak"
+    k = PRODUCTS[precision]
+    return (PEAK_16BIT_MFMA_TFLOPS / k,
+            f"dense 16-bit MFMA peak {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {k} MFMA products per f32-grade "
+            "product; achieved counts ALGORITHMIC flops")
+
+
+# ------------------------------------------------------------------------------------------------
+# ranks
+# ------------------------------------------------------------------------------------------------
 class Dist:
-    """One process per GPU; RCCL ('nccl') on GPUs, gloo for the CPU self-test."""
+    """One process per GPU; RCCL ('nccl') on GPUs, gloo for the CPU dry run."""
 
     def __init__(self, backend):
         import torch.distributed as dist
@@ -117,56 +151,155 @@ def timed_steps(d, step_fn, sync_fn, steps, warmup):
     return d.max_float(mine), mine
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed as is: start the N ranks as FRESH child processes (this
+    parent has made no HIP call and never will), one per GPU, rendezvous on 127.0.0.1.  Rank 0's
+    stdout is ours (its JSON line goes straight through); the first failing rank ends the run."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NRV_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:                      # one rank died: the others would wait in the barrier forever
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+class DryRunEngine:
+    """Stand-in for the engine in `--dry-run` (CPU, gloo): exercises launch, sharding, barriers,
+    the max-over-ranks timing and the JSON line; it revises nothing and its rate means nothing."""
+
+    def __init__(self, batch, T, seed):
+        self.x = np.random.default_rng(seed).standard_normal((batch, T * 6)).astype(np.float32)
+        self.n = 0
+
+    def step(self):
+        self.n += int(np.tanh(self.x).argmax(-1).shape[0])
+
+
 def run_distributed_cpu_selftest(batch=4096, steps=3):
-    """CPU / gloo exercise of the N>1 control path (tests/test_shard_gloo.py): same Dist class,
-    same timed_steps, same shard arithmetic; the step itself is a sleep."""
+    """CPU / gloo exercise of the N>1 control path inside an already-spawned rank (tests/
+    test_shard_gloo.py): the Dist class, timed_steps and the shard arithmetic of the real run over
+    the dry-run engine's step loop."""
     from nanoreviser_amd import shard
     d = Dist("gloo")
     lo, hi = shard.shard_range(d.world * batch, d.rank, d.world)
-    done = {"n": 0}
-
-    def step():
-        time.sleep(0.01 * (d.rank + 1))
-        done["n"] += hi - lo
-
-    mx, mine = timed_steps(d, step, lambda: None, steps, 1)
-    total = d.sum_int((hi - lo) * steps)
+    eng = DryRunEngine(hi - lo, 13, 20260 + d.rank)
+    mx, mine = timed_steps(d, eng.step, lambda: None, steps, 1)
+    total = d.sum_int(eng.n - (hi - lo))               # the warm-up step is not counted
     d.close()
     return {"total_units": total, "max_ms": mx * 1e3, "my_ms": mine * 1e3, "shard": (lo, hi)}
 
 
-def cpu_baseline(m1, m2, T, sig, rd, target_s=15.0):
-    """oracle/nrv_oracle.c on all host cores, bounded to ~target_s of CPU work."""
-    from oracle import c_oracle as CO
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (oracle/ is the checker and the reported baseline, never the product)
+# ------------------------------------------------------------------------------------------------
+def host_cores():
     try:
-        cores = len(os.sched_getaffinity(0))
+        aff = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        aff = list(range(os.cpu_count() or 1))
+    cores = len(aff)
+    quota = None
     try:                                   # a cgroup CPU quota caps what the threads can really use
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
-            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+            quota = float(q) / float(per)
+            cores = max(1, min(cores, int(quota + 0.5)))
     except Exception:
         pass
+    return cores, aff, quota
+
+
+def _mask_str(aff):
+    """Affinity list as ranges: [0,1,2,3,8,9] -> '0-3,8-9'."""
+    out, i = [], 0
+    while i < len(aff):
+        j = i
+        while j + 1 < len(aff) and aff[j + 1] == aff[j] + 1:
+            j += 1
+        out.append(str(aff[i]) if i == j else f"{aff[i]}-{aff[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def host_stage_us_per_base():
+    """The product's own host stage (a14/a15 counterparts: event collapse, medians, per-event stats,
+    feature rows; windows are cut on the device) on one fixture read, one core."""
+    from nanoreviser_amd import hoststage as hs
+    p = os.path.join(ROOT, "tests", "golden", "reads", "ch13_read2251.npz")
+    if not os.path.exists(p):
+        return None
+    g = np.load(p)
+    cols = [g[k] for k in ("ev_start", "ev_mean", "ev_stdv", "ev_model_state", "ev_move", "raw_signal")]
+    best, n = None, 0
+    for _ in range(5):
+        t0 = time.perf_counter()
+        rd = hs.collapse_events(*cols)
+        rt = hs.read_tensors_raw(rd)
+        dt = time.perf_counter() - t0
+        n = len(rt.feat_ev)
+        best = dt if best is None else min(best, dt)
+    return {"value": best / n * 1e6, "unit": "us/base", "cores": 1,
+            "what": "nanoreviser_amd.hoststage collapse_events + read_tensors_raw on fixture read ch13_read2251 "
+                    f"({n} bases), best of 5; windows are cut on the device (segment_kernel)",
+            "reference_python_loop_us_per_base": 42.0,
+            "reference_note": "preprocessing.py:85-170 signal_segmentation measured at survey time in the build "
+                              "container (SURVEY.md 6); /root/reference does not exist on the GPU box"}
+
+
+def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
+    """oracle/nrv_oracle.c on all host cores (bounded to ~target_s) and on one thread (~target_s/2)."""
+    from oracle import c_oracle as CO
+    cores, aff, quota = host_cores()
     f1, f2 = m1.flat(), m2.flat()
 
-    def run(n):
+    def run(n, threads):
         t0 = time.perf_counter()
-        CO.predict(f1, T, 6, sig[:n], rd[:n], threads=cores)
-        CO.predict(f2, T, 5, sig[:n], rd[:n], threads=cores)
+        CO.predict(f1, T, 6, sig[:n], rd[:n], threads=threads)
+        CO.predict(f2, T, 5, sig[:n], rd[:n], threads=threads)
         return time.perf_counter() - t0
 
-    n0 = min(len(rd), 8 * cores)
-    t_cal = run(n0)
-    n = int(min(len(rd), max(n0, n0 * target_s / max(t_cal, 1e-3))))
-    t = run(n)
-    if t < 0.5 * target_s and n == len(rd):          # whole step was too quick: repeat it
-        reps = int(min(64, max(1, target_s / max(t, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            run(n)
-        t = time.perf_counter() - t0
-        n *= reps
+    def bounded(threads, budget):
+        n0 = min(len(rd), 8 * threads)
+        t_cal = run(n0, threads)
+        n = int(min(len(rd), max(n0, n0 * budget / max(t_cal, 1e-3))))
+        t = run(n, threads)
+        if t < 0.5 * budget and n == len(rd):            # whole step was too quick: repeat it
+            reps = int(min(64, max(1, budget / max(t, 1e-3))))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run(n, threads)
+            t = time.perf_counter() - t0
+            n *= reps
+        return n, t
+
+    n, t = bounded(cores, target_s)
+    n1, t1 = bounded(1, target_s / 2)
     ref = "unavailable on this host"
     try:
         import keras  # noqa: F401
@@ -177,50 +310,208 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=15.0):
     return {"value": n / t, "unit": "bases/s", "cores": cores, "kind": "port",
             "sample": f"{n} windows drawn from the step's {len(rd)} synthetic windows (T={T}), model1+model2, "
                       f"oracle/nrv_oracle.c with {cores} OpenMP threads, {t:.1f} s",
-            "reference_keras_tf": ref}
+            "one_thread": {"value": n1 / t1, "unit": "bases/s", "cores": 1,
+                           "sample": f"{n1} windows, 1 thread, {t1:.1f} s"},
+            "affinity": {"mask": _mask_str(aff), "n": len(aff), "os_cpu_count": os.cpu_count(),
+                         "cgroup_cpu_quota": quota},
+            "host_stage_us_per_base": host_stage_us_per_base(),
+            "reference_keras_tf": ref,
+            "note": "kind 'port': the reference's path is Python on keras 2.2.4 / tensorflow 1.12, which cannot be "
+                    "installed here; the C port restates the same graph.  Reported baseline only - a GPU/CPU ratio "
+                    "says nothing about kernel quality, the roofline fraction does."}
 
 
 def load_traffic(T, batch, precision):
     """HBM bytes per lstm3 launch from the committed PMC pass (profiles/*.json), else None."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_lstm3.json")
-    try:
-        j = json.load(open(p))
-        j = j.get(precision, j)
-        if j.get("T") == T and j.get("batch") == batch:
-            return j.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    for name in ("r02_pmc_lstm3.json", "r01_pmc_lstm3.json"):
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+            j = j.get(precision)
+            if j and j.get("T") == T and j.get("batch") == batch:
+                return j.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
-    ap.add_argument("--window", type=int, default=13, help="events per window (T)")
-    ap.add_argument("--species", default="ecoli")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
-                    help="matrix arithmetic of the three large Bi-LSTM layers (include/nanorev.h)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--prof-all", action="store_true",
-                    help="time every kernel (7 event records per step) instead of only the dominant one")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------
+# secondary measurements (rank 0, one GPU)
+# ------------------------------------------------------------------------------------------------
+def _time_calls(fn, sync, reps, warm=1):
+    for _ in range(warm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
 
+
+def fixture_reads():
+    """The five fixture reads (unitest/test_data/fast5, pre-extracted: tests/golden/reads) through the
+    product's host stage -> RawReadTensors list."""
+    from nanoreviser_amd import hoststage as hs
+    idx = json.load(open(os.path.join(ROOT, "tests", "golden", "reads", "index.json")))
+    out = []
+    for e in idx:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "reads", e["key"] + ".npz"))
+        rd = hs.collapse_events(g["ev_start"], g["ev_mean"], g["ev_stdv"], g["ev_model_state"], g["ev_move"],
+                                g["raw_signal"])
+        out.append(hs.read_tensors_raw(rd))
+    return out
+
+
+def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step):
+    from nanoreviser_amd.engine import Reviser
+    from nanoreviser_amd.weights import load_species
+    from nanoreviser_amd import workload as W
+    T, B = args.window, args.batch
+    out = {}
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def outputs(n):
+        return (torch.empty(n, 6, device=dev), torch.empty(n, 5, device=dev),
+                torch.empty(n, dtype=torch.int8, device=dev), torch.empty(n, dtype=torch.int8, device=dev))
+
+    # ---- f32 mode: the same step on plain f32 matrix instructions
+    rv = Reviser(m1, m2, device=local_rank, batch=B, precision="f32")
+    rv.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_sig, d_rd = torch.from_numpy(sig).to(dev), torch.from_numpy(rd).to(dev)
+    o = outputs(B)
+    ptrs = (d_sig.data_ptr(), d_rd.data_ptr(), B) + tuple(x.data_ptr() for x in o)
+    ms = _time_calls(lambda: rv.predict_device(*ptrs), sync, max(10, min(args.steps, 50)), warm=10) * 1e3
+    rv.prof_enable(2)
+    rv.prof_read()
+    for _ in range(16):
+        rv.predict_device(*ptrs)
+    sync()
+    pr = rv.prof_read()
+    k3 = list(pr.keys())[3]
+    us3 = pr[k3][0] / max(pr[k3][1], 1) * 1e3
+    whole = flop_per_window(T) * B / (ms * 1e-3) / 1e12
+    out["f32_mode"] = {"ms_per_step": ms, "bases_per_s": B / (ms * 1e-3),
+                       "whole_step_tflops": whole, "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
+                       "lstm3_us": us3,
+                       "lstm3_frac_of_f32_mfma_peak": flop_lstm3_launch(T, B) / (us3 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    rv.close()
+    del d_sig, d_rd
+
+    # ---- host-inclusive: inputs and outputs in HOST memory, H2D / D2H inside the timed call
+    rv = Reviser(m1, m2, device=local_rank, batch=B, precision=args.precision)
+    G = 8
+    hsig, hrd = np.tile(sig, (G, 1, 1)), np.tile(rd, (G, 1, 1))
+    dt = _time_calls(lambda: rv.predict_pair(hsig, hrd), lambda: None, 3)
+    hi = {"nrv_predict": {"bases_per_s": G * B / dt, "windows": G * B,
+                          "bytes_per_base_over_pcie": T * 56 * 4 + 11 * 4 + 2,
+                          "vs_device_resident": (G * B / dt) / (B / (dev_ms_per_step * 1e-3))}}
+    del hsig, hrd
+    out["host_inclusive"] = hi
+    rv.close()
+
+    # ---- C5: one long read, human weights, streamed in device-formed window groups
+    h1, h2 = load_species("human")
+    h1, h2 = h1.with_window(T), h2.with_window(T)
+    rv = Reviser(h1, h2, device=local_rank, batch=B, precision=args.precision)
+    rv.set_stream(torch.cuda.current_stream().cuda_stream)
+    N = 200_000
+    sev, fev = W.synth_read(N)
+    d_sev, d_fev = torch.from_numpy(sev).to(dev), torch.from_numpy(fev).to(dev)
+    o = outputs(N - T)
+    rp = (d_sev.data_ptr(), d_fev.data_ptr(), N) + tuple(x.data_ptr() for x in o)
+    dt = _time_calls(lambda: rv.predict_read_device(*rp), sync, 5)
+    fl = FLOP_PER_BASE_DEDUP.get(T, flop_per_window(T))
+    peak, _ = mode_peak(args.precision)
+    ach = (N - T) * fl / dt / 1e12
+    out["read_mode"] = {"config": f"C5: human weights, one synthetic read of {N} events, T={T}, device-formed windows "
+                                  f"in groups of {B}, inputs resident in HBM",
+                        "bases_per_s": (N - T) / dt, "flop_per_base_dedup": fl, "achieved_tflops": ach,
+                        "frac": ach / peak, "peak": peak}
+    dt = _time_calls(lambda: rv.predict_read(sev, fev), lambda: None, 3)
+    hi["nrv_predict_read"] = {"bases_per_s": (N - T) / dt, "events": N, "bytes_per_base_over_pcie": 224 + 46,
+                              "vs_device_resident": ((N - T) / dt) / out["read_mode"]["bases_per_s"]}
+    rv.close()
+    del d_sev, d_fev
+
+    # ---- C2 / C3: the fixture reads (T = 11, shipped weights), replicated
+    try:
+        reads = fixture_reads()
+    except Exception as e:                                   # fixtures missing: say so, do not invent
+        out["configs"] = {"error": repr(e)}
+        return out
+    sev = np.concatenate([r.sig_ev for r in reads])
+    fev = np.concatenate([r.feat_ev for r in reads])
+    nb = sum(len(r.feat_ev) for r in reads)
+    cfg = {}
+    for name, sp, batch, reps in (("C2", "ecoli", 512, 10), ("C3", "human", 4096, 40)):
+        a, b = load_species(sp)
+        rv = Reviser(a, b, device=local_rank, batch=batch, precision=args.precision)
+        rv.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_sev, d_fev = torch.from_numpy(sev).to(dev), torch.from_numpy(fev).to(dev)
+        n = len(fev) - a.T
+        o = outputs(n)
+        rp = (d_sev.data_ptr(), d_fev.data_ptr(), len(fev)) + tuple(x.data_ptr() for x in o)
+        dt = _time_calls(lambda: rv.predict_read_device(*rp), sync, reps)
+        raws = [[r.raw for r in reads], [r.starts for r in reads], [r.feat_ev for r in reads],
+                [r.shift for r in reads], [r.scale for r in reads]]
+        dth = _time_calls(lambda: rv.predict_reads_raw(*raws), lambda: None, max(2, reps // 4))
+        cfg[name] = {"config": f"{sp} weights, T={a.T}, batch={batch} windows per launch group, the five fixture reads "
+                               f"({nb} bases) x {reps} = {5 * reps} reads; fast5 parsing excluded",
+                     "bases_per_s_device_resident": n / dt,
+                     "bases_per_s_host_inclusive_raw_reads": n / dth,
+                     "achieved_tflops": n * FLOP_PER_BASE_DEDUP[11] / dt / 1e12}
+        rv.close()
+    out["configs"] = cfg
+    hi["nrv_predict_reads_raw"] = {"bases_per_s": cfg["C3"]["bases_per_s_host_inclusive_raw_reads"],
+                                   "bytes_per_base_over_pcie": 46 + 46,
+                                   "vs_device_resident": cfg["C3"]["bases_per_s_host_inclusive_raw_reads"]
+                                   / cfg["C3"]["bases_per_s_device_resident"]}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def check_world(args):
+    """Before any rendezvous: a launcher's WORLD_SIZE and --gpus must agree."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree "
+                 "(plain `python bench.py --gpus N` starts its own ranks)")
+
+
+def run_dry(args):
+    """--dry-run: the whole control path on CPU (gloo), no engine, no GPU."""
+    from nanoreviser_amd import shard
+    check_world(args)
+    d = Dist("gloo")
+    lo, hi = shard.shard_range(d.world * args.batch, d.rank, d.world)
+    eng = DryRunEngine(hi - lo, args.window, 20260 + d.rank)
+    elapsed, _ = timed_steps(d, eng.step, lambda: None, args.steps, args.warmup)
+    total = d.sum_int((hi - lo) * args.steps)
+    if d.rank == 0:
+        print(json.dumps({
+            "metric": "bases revised/sec (whole node)", "value": total / elapsed, "unit": "bases/s",
+            "n_gpus": args.gpus, "world_size": d.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "none", "data": "dry-run (CPU control path only; no engine, rate is meaningless)",
+            "config": {"workload": "dry run", "batch_windows_per_gpu": args.batch, "window": args.window}}), flush=True)
+    d.close()
+    return 0
+
+
+def run_rank(args):
     import torch
     from nanoreviser_amd.engine import Reviser
     from nanoreviser_amd.weights import load_species
-    from oracle import nrv_oracle as O      # synthetic-window generator + smoke check only
+    from nanoreviser_amd import workload as W
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    check_world(args)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     d = Dist("nccl")
 
@@ -231,7 +522,7 @@ def main():
     stream = torch.cuda.current_stream()
     rv.set_stream(stream.cuda_stream)
 
-    sig, rd = O.synth_windows(B, T, seed=20260 + d.rank)     # each rank owns its own shard
+    sig, rd = W.synth_windows(B, T, seed=20260 + d.rank)     # each rank owns its own shard
     dev = f"cuda:{local_rank}"
     d_sig, d_rd = torch.from_numpy(sig).to(dev), torch.from_numpy(rd).to(dev)
     p1 = torch.empty(B, 6, device=dev)
@@ -246,48 +537,62 @@ def main():
     def sync():
         torch.cuda.synchronize()
 
-    # correctness guard before timing anything: 64 windows against the fp64 oracle
+    # correctness guard before timing anything: 64 windows against the fp64 oracle (the checker)
+    from oracle import nrv_oracle as O
     step(); sync()
     q1, q2, b1, b2 = O.predict_pair(m1.tensors, m2.tensors, sig[:64], rd[:64], np.float64)
     dp = max(float(np.abs(p1[:64].cpu().numpy() - q1).max()), float(np.abs(p2[:64].cpu().numpy() - q2).max()))
     if dp > 1e-4 or not (np.array_equal(a1[:64].cpu().numpy(), b1) and np.array_equal(a2[:64].cpu().numpy(), b2)):
         sys.exit(f"bench.py: HIP path disagrees with the oracle (max|dp|={dp:.2e}); refusing to time it")
 
-    # Untimed priming burst.  The first unsynchronised burst of launches of a process pays a one-off
-    # ~35 ms (measured: 60 queued steps take 76-82 ms the first time, 43 ms ever after, whatever the
-    # idle time in between); with a short --warmup it would land inside the timed region.
-    for _ in range(64):
+    # Untimed priming.  The first unsynchronised burst of launches of a process pays a one-off ~35 ms
+    # (60 queued steps: 76-82 ms the first time, 43 ms ever after), and the chip needs ~0.2 s of load to
+    # settle on the clock it sustains; with a short --warmup both would land inside the timed region.
+    for _ in range(args.prime):
         step()
     sync()
+    prof_mode = 0
     if not args.no_prof:
-        # every 8th launch of the dominant kernel is bracketed; every launch when the run is short
-        prof_mode = 1 if args.prof_all else (3 if args.steps >= 64 else 2)
+        prof_mode = 1 if args.prof_all else 3            # 3: the dominant kernel, every 8th launch
         rv.prof_enable(prof_mode)
         rv.prof_read()
     for _ in range(args.warmup):
         step()
     sync()
-    if not args.no_prof:
-        rv.prof_read()                                   # discard warm-up launches
+    if prof_mode:
+        rv.prof_enable(prof_mode)                        # restart the every-8th tick; drops warm-up samples
+        rv.prof_read()
     elapsed, _ = timed_steps(d, step, sync, args.steps, 0)
-    prof = rv.prof_read() if not args.no_prof else {}
+    prof = rv.prof_read() if prof_mode else {}
     total = d.sum_int(B * args.steps)
     value = total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
+    # untimed pass: every kernel bracketed (7 event records per step would perturb the timed region)
+    kernel_us = {}
+    if prof_mode and d.rank == 0:
+        rv.prof_enable(1)
+        rv.prof_read()
+        for _ in range(max(8, min(args.steps, 32))):
+            step()
+        sync()
+        kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in rv.prof_read().items() if c > 0}
+    rv.prof_enable(0)
+
+    peak, peak_note = mode_peak(args.precision)
     out = {
         "metric": "bases revised/sec (whole node)", "value": value, "unit": "bases/s",
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": args.gpus, "world_size": d.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 via 3xbf16 split (f32 accumulate)",
+        "dtype": DTYPE[args.precision],
         "data": "synthetic",
         "config": {
             "workload": f"{args.species} weights, synthetic independent {T}-event windows (SURVEY 8d C4 "
                         f"generator), batch={B} windows per GPU per step, model1+model2"
                         + ("; T=13 uses the shipped weights + seeded synthetic (78,16) feature kernel" if T != 11 else ""),
             "species": args.species, "window": T, "batch_windows_per_gpu": B,
-            "precision": args.precision + (" (f32 operands split exactly into 3 bf16 terms, 6 MFMA products, "
-                                           "f32 accumulate)" if args.precision == "bf16x3" else ""),
+            "precision": args.precision,
             "parallelism": f"read/window-sharded x{args.gpus}, no collectives",
             "parity_guard_max_abs_dp": dp,
         },
@@ -295,27 +600,27 @@ def main():
     if d.rank == 0:
         if prof:
             names = list(prof.keys())
-            per_kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in prof.items() if c > 0}
             k3 = names[3]
-            avg_s = prof[k3][0] / max(prof[k3][1], 1) * 1e-3
+            if prof[k3][1] > 0:
+                avg_s = prof[k3][0] / prof[k3][1] * 1e-3
+                where = "hipEvent pairs on the launch stream inside the timed region" + \
+                    (", every 8th launch bracketed" if prof_mode == 3 else "")
+                n_l = prof[k3][1]
+            else:                                             # fewer than one sampled launch: use the untimed pass
+                avg_s = kernel_us[k3] * 1e-6
+                where, n_l = "hipEvent pairs on the launch stream, untimed pass right after the timed region", 0
             fl = flop_lstm3_launch(T, B, executed=True)
             ach = fl / avg_s / 1e12
-            if args.precision == "bf16x3":
-                peak = PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS
-                peak_note = (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {BF16X3_PRODUCTS} products "
-                             "per f32-exact product; achieved counts ALGORITHMIC flops")
-            else:
-                peak = PEAK_F32_MFMA_TFLOPS
-                peak_note = "dense f32 MFMA peak"
+            kname = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
+                     "f16x2": "lstm_h2_kernel<192,128>"}[args.precision]
             out["roofline"] = {
-                "kernel": ("lstm_split_kernel<32,16,128,2,1> " if args.precision == "bf16x3"
-                           else "lstm_layer_kernel<32,16,128,1,1> ") + f"({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
+                "kernel": f"{kname} ({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": load_traffic(T, B, args.precision),
-                "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": prof[k3][1],
-                "timing": "hipEvent pairs on the launch stream inside the timed region" + (", every 8th launch bracketed" if prof_mode == 3 else ""),
-                "peak_note": peak_note,
-                "executed_tflops": ach * (BF16X3_PRODUCTS if args.precision == "bf16x3" else 1),
+                "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": n_l,
+                "avg_launch_us_untimed_pass": kernel_us.get(k3),
+                "timing": where, "peak_note": peak_note,
+                "executed_tflops": ach * PRODUCTS[args.precision],
                 "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
             }
             whole = flop_per_window(T) * B / (ms_per_step * 1e-3) / 1e12
@@ -323,13 +628,49 @@ def main():
                                           "frac": whole / peak,
                                           "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
                                           "flop_per_window": flop_per_window(T)}
-            out["kernel_us"] = per_kernel_us
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m1, m2, T, sig, rd)
-        print(json.dumps(out), flush=True)
+            out["kernel_us"] = kernel_us
+            out["kernel_us_sum"] = sum(kernel_us.values())
     rv.close()
+    if d.rank == 0 and args.gpus == 1 and not args.no_extras:
+        del d_sig, d_rd
+        try:
+            out.update(extras(args, torch, dev, local_rank, m1, m2, sig, rd, ms_per_step))
+        except Exception as e:                               # never lose the main line to a secondary block
+            out["extras_error"] = repr(e)
+    if d.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(m1, m2, T, sig, rd)
+    if d.rank == 0:
+        print(json.dumps(out), flush=True)
     d.close()
+    return 0
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
+    ap.add_argument("--window", type=int, default=13, help="events per window (T)")
+    ap.add_argument("--species", default="ecoli")
+    ap.add_argument("--precision", default=os.environ.get("NRV_BENCH_PRECISION", "bf16x3"),
+                    choices=sorted(PRODUCTS), help="matrix arithmetic (include/nanorev.h, nrv_set_precision)")
+    ap.add_argument("--prime", type=int, default=300, help="untimed steps before the warm-up (clock settling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract keys + roofline")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--prof-all", action="store_true",
+                    help="time every kernel INSIDE the timed region (7 event records per step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU / gloo run of the launch + sharding + timing control path (no engine)")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)
+    return run_dry(args) if args.dry_run else run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -108,7 +108,11 @@ def parse_read(path: str, group: str, subgroup: str):
         start = start * 4000 - d["raw_attrs"]["start_time"]
         length = length * 4000
     rd = hs.collapse_events(start, ev["mean"], ev["stdv"], ev["model_state"], ev["move"], d["signal"])
-    fq = d["fastq"].decode("utf8") if d["fastq"] is not None else None
+    fq = d["fastq"]                           # bytes (fixed-length string dataset) or str (variable-length)
+    if isinstance(fq, (bytes, np.bytes_)):
+        fq = bytes(fq).decode("utf8", "replace")
+    elif fq is not None:
+        fq = str(fq)
     return rd, fq
 
 
@@ -324,9 +328,9 @@ def _default_factory(args, device: int):
     return Reviser(load_model(p1), load_model(p2), device=device, batch=args.batch)
 
 
-def _worker(rank: int, world: int, args, files: List[str], q):
+def _worker(rank: int, world: int, args, files: List[str], q, factory=None):
     try:
-        rv = _default_factory(args, rank)
+        rv = (factory or _default_factory)(args, rank)
         st = process_files(args, files, rv, print)
         rv.close()
         q.put((rank, st, None))
@@ -334,11 +338,76 @@ def _worker(rank: int, world: int, args, files: List[str], q):
         q.put((rank, None, repr(e)))
 
 
-def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone: bool = False) -> int:
+def write_originals(args, files: Sequence[str], log: Callable[[str], None]) -> List[str]:
+    """The failure contract for reads whose WORKER is gone (NanoReviser.py:146-152 / :173-179): every
+    file of the shard that has no output yet gets its original basecalls written by this process.
+    Returns the files handled (all of them count as failed reads)."""
+    done = []
+    for fn in files:
+        if os.path.exists(out_name(args.output_dir, fn, args.output_format)):
+            continue
+        done.append(fn)
+        try:
+            rd, fq = parse_read(os.path.join(args.fast5_base_dir, fn), args.basecall_group, args.basecall_subgroup)
+            if args.output_format == "fastq" and fq is not None:
+                b, q = hs.trim_fastq(fq)
+                write_read(args, fn, b, q)
+            else:
+                write_read(args, fn, "".join(x.decode() for x in np.asarray(rd.bases).tolist()), None)
+        except Exception as e:
+            log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {e!r}")
+    return done
+
+
+def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2):
+    """One worker process per GPU (NanoReviser.py:203-219 fans out the same way, one Pool task per
+    file).  The parent never blocks on the result queue alone: a worker that dies hard - a HIP memory
+    fault aborts the process, a segfault, the OOM killer - posts nothing, so liveness is polled next to
+    the queue.  The other workers finish their own shards (reads are independent).
+    Returns [(rank, stats or None, error or None)]."""
+    import multiprocessing as mp
+    import queue as _q
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = len(shards)
+    procs = [ctx.Process(target=_worker, args=(r, world, args, shards[r], q, factory)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = {}
+
+    def drain(timeout):
+        try:
+            while True:
+                rank, st, err = q.get(timeout=timeout)
+                res[rank] = (rank, st, err)
+                timeout = 0.0
+        except _q.Empty:
+            pass
+
+    while len(res) < world:
+        drain(poll_s)
+        for r, pr in enumerate(procs):
+            if r not in res and not pr.is_alive():
+                drain(0.5)                            # its last message may still be in the pipe
+                if r not in res:
+                    res[r] = (r, None, f"worker {r} died without reporting (exit code {pr.exitcode})")
+    for pr in procs:
+        pr.join(30)
+        if pr.is_alive():
+            pr.terminate()
+    return [res[r] for r in range(world)]
+
+
+def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone: bool = False,
+         worker_factory=None, world: Optional[int] = None) -> int:
     """standalone=True (the NanoReviser.py entry point): this process is only the command line, so the
     engine is loaded without importing torch first (~1.5 s of start-up).  Library callers keep the
-    default: engine.load_library imports torch first so that one HIP runtime serves both."""
+    default: engine.load_library imports torch first so that one HIP runtime serves both.
+    worker_factory (a picklable module-level callable (args, device) -> engine) and world replace the
+    engine constructor and the device count in the multi-process path (tests).
+    Returns 0, 2 (nothing could run) or 3 (a GPU worker was lost; its reads were written unrevised)."""
     args = get_args(argv)
+    rc = 0
     if args.output_format not in ("fasta", "fastq"):
         print("[！！！Error] output_format must be fasta or fastq", file=sys.stderr)
         return 2
@@ -354,9 +423,11 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         # torch first only so that a LATER torch import in the same process finds one HIP runtime.)
         if standalone and "torch" not in sys.modules:
             os.environ.setdefault("NRV_NO_TORCH", "1")
-        import multiprocessing as mp
-        from .engine import device_count
-        ndev = device_count()
+        if world is not None:
+            ndev = int(world)
+        else:
+            from .engine import device_count
+            ndev = device_count()
         if ndev == 0:
             print("[！！！Error] no MI355X / HIP device visible: the reviser has no CPU path", file=sys.stderr)
             return 2
@@ -364,24 +435,20 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         sizes = [os.path.getsize(os.path.join(args.fast5_base_dir, f)) for f in names]
         parts = shard_reads(sizes, world)
         if world == 1:
-            rv = _default_factory(args, 0)
+            rv = (worker_factory or _default_factory)(args, 0)
             stats = [process_files(args, names, rv, print)]
             rv.close()
         else:
-            ctx = mp.get_context("spawn")
-            q = ctx.Queue()
-            procs = [ctx.Process(target=_worker, args=(r, world, args, [names[i] for i in parts[r]], q))
-                     for r in range(world)]
-            for pr in procs:
-                pr.start()
-            res = [q.get() for _ in procs]
-            for pr in procs:
-                pr.join()
-            bad = [e for _, s, e in res if s is None]
-            if bad:
-                print(f"[！！！Error] worker failed: {bad[0]}", file=sys.stderr)
-                return 2
-            stats = [s for _, s, _ in res]
+            shards = [[names[i] for i in parts[r]] for r in range(world)]
+            res = run_workers(args, shards, worker_factory)
+            stats = [s for _, s, _ in res if s is not None]
+            for r, s_, e in res:
+                if s_ is None:                        # the shard's files still get an output + a failed_reads entry
+                    print(f"[！！！Error] GPU worker {r} failed: {e}; writing the original basecalls of its "
+                          f"unfinished reads", file=sys.stderr)
+                    lost = write_originals(args, shards[r], print)
+                    stats.append({"reads": len(shards[r]), "bases": 0, "failed": lost, "host_s": 0.0, "engine_s": 0.0})
+                    rc = 3
     failed = [f for s in stats for f in s["failed"]]
     with open(os.path.join(args.output_dir, args.failed_reads_filename), "w") as fp:
         fp.write("".join(f + "\n" for f in failed))
@@ -394,7 +461,7 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
               f"{nb / max(dt, 1e-9):.0f} bases/s end to end "
               f"(host stage {sum(s['host_s'] for s in stats):.1f} s summed over workers, "
               f"engine thread {sum(s['engine_s'] for s in stats):.1f} s)")
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

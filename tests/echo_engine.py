@@ -1,0 +1,67 @@
+"""Stand-in engines for the command-line tests (host logic only, no compute).  Module-level so that
+spawned worker processes can unpickle the factories."""
+import os
+
+import numpy as np
+
+
+class EchoEngine:
+    """Stand-in for engine.Reviser in host-logic tests: 'predicts' exactly the original base at
+    every window centre (model1 label, model2 label-1), so revise_read must return the input."""
+    T = 11
+
+    def __init__(self, fail_marker=None):
+        self.fail_marker, self.calls = fail_marker, 0
+
+    def predict_read(self, sig_ev, feat_ev):
+        self.calls += 1
+        # fails on every call whose first event is the marked read's first event: the batched call
+        # (marked read first) AND the per-read retry of that read, but not the other reads' retries
+        if self.fail_marker is not None and np.array_equal(feat_ev[0], self.fail_marker):
+            raise RuntimeError("injected engine failure")
+        assert sig_ev.dtype == np.float32 and sig_ev.shape[1] == 50 and feat_ev.shape[1] == 6
+        n = len(feat_ev) - self.T
+        col = np.rint(feat_ev[:, 0] * 300).astype(int)                 # 250/180/100/30 -> A/G/T/C
+        lab = np.select([col == 250, col == 180, col == 100, col == 30], [5, 4, 3, 2])
+        a1 = lab[5:5 + n].astype(np.int8)
+        p1 = np.eye(6, dtype=np.float32)[a1] * 0.9 + 0.1 / 6
+        p2 = np.eye(5, dtype=np.float32)[a1 - 1] * 0.9 + 0.1 / 5
+        return p1, p2, a1, (a1 - 1).astype(np.int8)
+
+    def close(self):
+        pass
+
+    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
+        """What the CLI's workers hand over (engine.Reviser.predict_reads_raw): cut the windows with
+        the host stage here and go through the same echo."""
+        from nanoreviser_amd import hoststage as hs
+        for r, s in zip(raws, starts):
+            assert r.dtype == np.int16 and s.dtype == np.int32
+        sig = np.concatenate([hs.segment_windows_f32(r, s, sh, sc) for r, s, sh, sc in zip(raws, starts, shifts, scales)])
+        return self.predict_read(sig, np.concatenate(feats))
+
+
+def echo_factory(args, device):
+    return EchoEngine()
+
+
+def dying_factory(args, device):
+    """Worker on 'GPU' 1 dies before it has an engine."""
+    if device == 1:
+        os._exit(1)
+    return EchoEngine()
+
+
+class _DiesInPredict(EchoEngine):
+    def predict_read(self, sig_ev, feat_ev):
+        os._exit(134)                      # what an abort() inside the native library looks like
+
+
+def dying_midway_factory(args, device):
+    return _DiesInPredict() if device == 1 else EchoEngine()
+
+
+def broken_factory(args, device):
+    if device == 1:
+        raise RuntimeError("libnanorev_hip: error -3: no HIP device")
+    return EchoEngine()

@@ -10,41 +10,9 @@ import pytest
 from conftest import GOLD, load_read
 from nanoreviser_amd import cli
 from nanoreviser_amd import hoststage as hs
+from echo_engine import EchoEngine, echo_factory, dying_factory, dying_midway_factory, broken_factory
 
 FAST5 = os.path.join(GOLD, "fast5")
-
-
-class EchoEngine:
-    """Stand-in for engine.Reviser in host-logic tests: 'predicts' exactly the original base at
-    every window centre (model1 label, model2 label-1), so revise_read must return the input."""
-    T = 11
-
-    def __init__(self, fail_marker=None):
-        self.fail_marker, self.calls = fail_marker, 0
-
-    def predict_read(self, sig_ev, feat_ev):
-        self.calls += 1
-        # fails on every call whose first event is the marked read's first event: the batched call
-        # (marked read first) AND the per-read retry of that read, but not the other reads' retries
-        if self.fail_marker is not None and np.array_equal(feat_ev[0], self.fail_marker):
-            raise RuntimeError("injected engine failure")
-        assert sig_ev.dtype == np.float32 and sig_ev.shape[1] == 50 and feat_ev.shape[1] == 6
-        n = len(feat_ev) - self.T
-        col = np.rint(feat_ev[:, 0] * 300).astype(int)                 # 250/180/100/30 -> A/G/T/C
-        lab = np.select([col == 250, col == 180, col == 100, col == 30], [5, 4, 3, 2])
-        a1 = lab[5:5 + n].astype(np.int8)
-        p1 = np.eye(6, dtype=np.float32)[a1] * 0.9 + 0.1 / 6
-        p2 = np.eye(5, dtype=np.float32)[a1 - 1] * 0.9 + 0.1 / 5
-        return p1, p2, a1, (a1 - 1).astype(np.int8)
-
-    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
-        """What the CLI's workers hand over (engine.Reviser.predict_reads_raw): cut the windows with
-        the host stage here and go through the same echo."""
-        from nanoreviser_amd import hoststage as hs
-        for r, s in zip(raws, starts):
-            assert r.dtype == np.int16 and s.dtype == np.int32
-        sig = np.concatenate([hs.segment_windows_f32(r, s, sh, sc) for r, s, sh, sc in zip(raws, starts, shifts, scales)])
-        return self.predict_read(sig, np.concatenate(feats))
 
 
 def test_flag_surface_matches_reference():
@@ -138,6 +106,57 @@ def test_broken_fast5_is_logged_not_fatal(tmp_path):
     rc = cli.main(["-d", str(d), "-o", out, "-S", "ecoli"], reviser_factory=lambda a, dev: EchoEngine())
     assert rc == 0 and open(out + "failed_reads.txt").read().split() == ["broken.fast5"]
     assert not glob.glob(out + "*_out.fasta")
+
+
+def _orig(fn):
+    _, rd, _ = load_read("_".join(fn.split("_")[-3:-1]))
+    return "".join(b.decode() for b in rd.bases.tolist())
+
+
+def test_multi_gpu_worker_path_world2(tmp_path):
+    """cli.run_workers / _worker with two spawned worker processes (one per 'GPU') and an injected
+    engine factory: reads are sharded, both shards are revised, stats and failed_reads are merged."""
+    out = str(tmp_path) + "/o/"
+    rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1"], worker_factory=echo_factory, world=2)
+    assert rc == 0
+    for fn in sorted(os.listdir(FAST5)):
+        assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + _orig(fn)
+    assert open(out + "failed_reads.txt").read() == ""
+
+
+@pytest.mark.parametrize("factory", [dying_factory, dying_midway_factory, broken_factory])
+def test_multi_gpu_worker_that_dies_does_not_hang_the_cli(tmp_path, factory):
+    """A worker that dies hard (os._exit: what a HIP memory fault / segfault / OOM kill looks like
+    from outside) posts nothing to the result queue.  The parent must notice, let the other worker
+    finish, write the ORIGINAL basecalls for the dead worker's reads (NanoReviser.py:146-152), list
+    them in failed_reads and return non-zero.  broken_factory: the engine cannot be created (raises)."""
+    import time
+    out = str(tmp_path) + "/o/"
+    t0 = time.time()
+    rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1", "-e", "bad.txt"],
+                  worker_factory=factory, world=2)
+    assert rc == 3 and time.time() - t0 < 120
+    files = sorted(os.listdir(FAST5))
+    failed = open(out + "bad.txt").read().split()
+    assert len(failed) == 1 and failed[0] in files                     # the dead worker's single read
+    for fn in files:                                                   # every read still has an output
+        assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + _orig(fn)
+
+
+def test_vlen_string_fastq_does_not_discard_the_read(monkeypatch):
+    """h5lite returns str for variable-length string datasets: parse_read must take both."""
+    from nanoreviser_amd import h5lite
+    p = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))[0]
+    real = h5lite.read_fast5
+
+    def as_str(path, g, sg):
+        d = real(path, g, sg)
+        d["fastq"] = bytes(d["fastq"]).decode()
+        return d
+    want = cli.parse_read(p, "Basecall_1D_000", "BaseCalled_template")
+    monkeypatch.setattr(h5lite, "read_fast5", as_str)
+    rd, fq = cli.parse_read(p, "Basecall_1D_000", "BaseCalled_template")
+    assert fq == want[1] and isinstance(fq, str) and np.array_equal(rd.bases, want[0].bases)
 
 
 @pytest.mark.gpu

@@ -71,3 +71,47 @@ def test_bench_sharding_world2_gloo():
     assert res[0]["max_ms"] == res[1]["max_ms"]
     assert res[0]["max_ms"] >= max(res[0]["my_ms"], res[1]["my_ms"]) - 1e-6
     assert res[0]["shard"] != res[1]["shard"]
+
+
+def test_bench_gpus2_typed_as_is_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts both ranks itself
+    (gloo dry run of the launch / sharding / timing control path) and relays ONE JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert abs(j["value"] - 2 * 4096 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-3 * j["value"]
+
+
+def test_bench_refuses_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_bench_self_launch_propagates_a_dead_rank():
+    """A rank that dies must end the run with its exit code (the others would sit in the barrier)."""
+    import subprocess
+    import bench
+    code = ("import os,sys,time\n"
+            "sys.exit(7) if os.environ['RANK']=='1' else time.sleep(60)\n")
+    script = os.path.join(ROOT, "tests", "_dead_rank_tmp.py")
+    with open(script, "w") as fp:
+        fp.write(code)
+    try:
+        real = bench.__file__
+        bench.__file__ = script
+        t0 = __import__("time").time()
+        rc = bench.self_launch(2, [])
+        assert rc == 7 and __import__("time").time() - t0 < 30
+    finally:
+        bench.__file__ = real
+        os.remove(script)

@@ -51,14 +51,25 @@ def split_f16(x, n, ftz=False):
 def make_matmul(mode):
     if mode == "f32":
         return lambda a, b: a @ b
-    if mode in ("h3", "h4", "h3z"):
-        pairs = [(0, 0), (0, 1), (1, 0)] + ([(1, 1)] if mode == "h4" else [])
+    if mode in ("h3", "h4", "h3z", "h3s", "h4s", "h3sz"):
+        pairs = [(0, 0), (0, 1), (1, 0)] + ([(1, 1)] if mode.startswith("h4") else [])
+        scaled = "s" in mode[2:]
+
+        def pow2_scale(x):
+            """power of two that brings max|x| into [2^13, 2^14) (exact; f16 max is 65504)"""
+            m = float(np.abs(x).max())
+            return np.float32(2.0 ** (13 - np.floor(np.log2(m)))) if m > 0 else np.float32(1)
 
         def mmh(a, b):
-            A, B = split_f16(a, 2, mode == "h3z"), split_f16(b, 2, mode == "h3z")
+            if scaled:
+                sa, sb = pow2_scale(a), pow2_scale(b)
+                a, b = a * sa, b * sb
+            A, B = split_f16(a, 2, mode.endswith("z")), split_f16(b, 2, mode.endswith("z"))
             out = np.zeros((a.shape[0], b.shape[1]), np.float32)
             for i, j in sorted(pairs, key=lambda p: -(p[0] + p[1])):
                 out = out + (A[i] @ B[j])
+            if scaled:
+                out = out * (np.float32(1) / (sa * sb))
             return out
         return mmh
     nterm = 2 if mode == "x3" else 3
