@@ -18,6 +18,7 @@ thread_local std::string g_create_error = "";
 
 constexpr int kMaxT = kHeadMaxT;
 constexpr int kRowPad = 128;           // workspace rows are padded to a multiple of this
+constexpr int kOutBytes = 6 * 4 + 5 * 4 + 1 + 1;   // p1, p2, a1, a2 of one window
 
 // ---- tensor table of one model blob (Keras positional order) --------
 struct Blob {
@@ -296,8 +297,15 @@ struct nrv_handle {
   // two staging sets [set][..]: the upload of group g+1 (copy stream) overlaps the kernels of group g
   float *d_sig[2] = {0, 0}, *d_feat[2] = {0, 0}, *d_p[2][2] = {{0, 0}, {0, 0}};
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0};
+  hipStream_t copy_stream = nullptr;      // host -> device
+  hipStream_t d2h_stream = nullptr;       // device -> host (its own stream: an upload never queues behind a download)
+  hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0}, ev_out[2] = {0, 0};
+  // page-locked host staging: outputs always land here first (46 B per window); inputs only when the
+  // caller's arrays could not be registered in place (bounce copies)
+  char* pin_out[2] = {0, 0};
+  char *pin_sig[2] = {0, 0}, *pin_feat[2] = {0, 0};
+  size_t pin_sig_cap = 0, pin_feat_cap = 0;
+  int host_register = 1;                  // NRV_HOST_REGISTER=0: never hipHostRegister caller memory
   // raw-read entry points: samples, event starts and read descriptors of the current call
   int16_t* d_raw = nullptr;
   int32_t* d_starts = nullptr;
@@ -413,7 +421,10 @@ static void free_workspace(nrv_handle* h) {
   for (int st = 0; st < 2; ++st) {
     (void)hipFree(h->d_sig[st]); (void)hipFree(h->d_feat[st]);
     h->d_sig[st] = h->d_feat[st] = nullptr;
+    (void)hipHostFree(h->pin_out[st]); (void)hipHostFree(h->pin_sig[st]); (void)hipHostFree(h->pin_feat[st]);
+    h->pin_out[st] = h->pin_sig[st] = h->pin_feat[st] = nullptr;
   }
+  h->pin_sig_cap = h->pin_feat_cap = 0;
   h->cap_rows = 0;
 }
 
@@ -445,6 +456,7 @@ static int ensure_workspace(nrv_handle* h) {
   for (int st = 0; st < 2; ++st) {
     HIPCHK(h, hipMalloc(&h->d_sig[st], (size_t)rows * T * kSig * 4 + 4096));
     HIPCHK(h, hipMalloc(&h->d_feat[st], (size_t)rows * T * kFeat * 4 + 4096));
+    HIPCHK(h, hipHostMalloc((void**)&h->pin_out[st], (size_t)rows * kOutBytes, hipHostMallocDefault));
   }
   h->cap_rows = rows;
   return NRV_OK;
@@ -707,10 +719,13 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   e = hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault);
   if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete h; return NRV_E_HIP; }
   h->stream = h->own_stream;
-  bool ok = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking) == hipSuccess;
   for (int st = 0; st < 2 && ok; ++st)
     ok = hipEventCreateWithFlags(&h->ev_in[st], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_done[st], hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&h->ev_done[st], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_out[st], hipEventDisableTiming) == hipSuccess;
+  if (const char* e2 = getenv("NRV_HOST_REGISTER")) h->host_register = atoi(e2) != 0;
   if (!ok) { g_create_error = "nrv_create: could not create the copy stream / events"; nrv_destroy(h); return NRV_E_HIP; }
   if ((rc = upload_model(h, 0, b1, 6)) || (rc = upload_model(h, 1, b2, 5)) || (rc = ensure_workspace(h))) {
     g_create_error = h->err;
@@ -729,9 +744,11 @@ void nrv_destroy(nrv_handle* h) {
   for (int m = 0; m < 2; ++m) (void)hipFree(h->dm[m].all);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  if (h->d2h_stream) { (void)hipStreamSynchronize(h->d2h_stream); (void)hipStreamDestroy(h->d2h_stream); }
   for (int st = 0; st < 2; ++st) {
     if (h->ev_in[st]) (void)hipEventDestroy(h->ev_in[st]);
     if (h->ev_done[st]) (void)hipEventDestroy(h->ev_done[st]);
+    if (h->ev_out[st]) (void)hipEventDestroy(h->ev_out[st]);
   }
   (void)hipFree(h->d_raw); (void)hipFree(h->d_starts); (void)hipFree(h->d_reads);
   if (h->ev_raw) (void)hipEventDestroy(h->ev_raw);
@@ -864,8 +881,53 @@ static void launch_segment(nrv_handle* h, int n_reads, int64_t ev0, int n_ev, fl
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
 }
 
-// raw != 0: read mode with the per-event signal windows cut on the device from the samples already
-// uploaded by upload_raw() (sig is ignored)
+// Caller memory registered (page-locked in place) for the duration of one call.
+struct HostPin {
+  void* p = nullptr;
+  bool on = false;
+  bool pin(nrv_handle* h, const void* ptr, size_t bytes) {
+    // below a few MB the registration costs more than the bounce copy it saves
+    if (!h->host_register || !ptr || bytes < ((size_t)4 << 20)) return false;
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();                    // not registrable (e.g. a read-only mapping): bounce instead
+      return false;
+    }
+    p = const_cast<void*>(ptr);
+    on = true;
+    return true;
+  }
+  ~HostPin() {
+    if (!on) return;
+    (void)hipDeviceSynchronize();               // error paths: no DMA may still be reading the range
+    (void)hipHostUnregister(p);
+  }
+};
+
+static int grow_pinned(nrv_handle* h, char* (&buf)[2], size_t* cap, size_t need) {
+  if (need <= *cap) return NRV_OK;
+  for (int st = 0; st < 2; ++st) {
+    (void)hipHostFree(buf[st]);
+    buf[st] = nullptr;
+  }
+  *cap = 0;
+  for (int st = 0; st < 2; ++st) HIPCHK(h, hipHostMalloc((void**)&buf[st], need, hipHostMallocDefault));
+  *cap = need;
+  return NRV_OK;
+}
+
+// Host-pointer entry points.  raw_reads != 0: read mode with the per-event signal windows cut on the
+// device from the samples already uploaded by upload_raw() (sig is ignored).
+//
+// Pipeline over launch groups, two staging sets, three streams; every transfer is a true DMA from / to
+// PAGE-LOCKED memory, so the host thread never sits inside a copy:
+//   inputs   the caller's arrays are registered in place for the call (hipHostRegister) and copied
+//            straight from there; arrays too small to be worth it, or not registrable, are bounced
+//            through pinned staging by a host memcpy that overlaps the previous group's kernels;
+//   outputs  land in pinned staging (46 B per window) and are handed to the caller one group behind.
+//   h2d:      [wait done(g-2)] upload(g) -> in(g)
+//   compute:  wait in(g), out(g-2); kernels(g) -> done(g)
+//   d2h:      wait done(g); download(g) -> out(g)
+//   host:     wait out(g-1); copy it to the caller; stage group g+1
 static int predict_host(nrv_handle* h, const float* sig, const float* feat, int64_t n_in, bool read_mode,
                         float* p1, float* p2, int8_t* a1, int8_t* a2, int raw_reads = 0) {
   int rc = check_handle(h);
@@ -873,29 +935,50 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   if (n_in < 0 || (n_in > 0 && ((!sig && !raw_reads) || !feat))) { h->err = "nrv_predict: bad arguments"; return NRV_E_INVALID; }
   const int T = h->T;
   const int64_t n = read_mode ? n_in - T : n_in;
-  // Pipeline over launch groups with two staging sets.  All copies run on the copy stream:
-  //   upload(g) -> [compute stream: wait, kernels(g), record done(g)] -> download(g-1) -> upload(g+1) ...
-  // Copies from/to pageable host memory block the host, so the download of group g-1 is issued
-  // AFTER the kernels of group g are queued: while the host sits in it (and in the next upload),
-  // the GPU is already computing group g.
-  auto download = [&](int64_t s, int nb, int st) -> int {
-    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_done[st], 0));
-    if (p1) HIPCHK(h, hipMemcpyAsync(p1 + s * 6, h->d_p[st][0], (size_t)nb * 6 * 4, hipMemcpyDeviceToHost, h->copy_stream));
-    if (p2) HIPCHK(h, hipMemcpyAsync(p2 + s * 5, h->d_p[st][1], (size_t)nb * 5 * 4, hipMemcpyDeviceToHost, h->copy_stream));
-    if (a1) HIPCHK(h, hipMemcpyAsync(a1 + s, h->d_a[st][0], (size_t)nb, hipMemcpyDeviceToHost, h->copy_stream));
-    if (a2) HIPCHK(h, hipMemcpyAsync(a2 + s, h->d_a[st][1], (size_t)nb, hipMemcpyDeviceToHost, h->copy_stream));
+  if (n <= 0) return NRV_OK;
+  const size_t ev_all = read_mode ? (size_t)n_in : (size_t)n_in * T;
+  HostPin pin_s, pin_f;
+  const bool direct_s = !raw_reads && pin_s.pin(h, sig, ev_all * kSig * 4);
+  const bool direct_f = pin_f.pin(h, feat, ev_all * kFeat * 4);
+  const size_t ev_grp = read_mode ? (size_t)(h->batch + T - 1) : (size_t)h->batch * T;
+  if (!raw_reads && !direct_s && (rc = grow_pinned(h, h->pin_sig, &h->pin_sig_cap, ev_grp * kSig * 4))) return rc;
+  if (!direct_f && (rc = grow_pinned(h, h->pin_feat, &h->pin_feat_cap, ev_grp * kFeat * 4))) return rc;
+
+  auto finalize = [&](int64_t s, int nb, int st) -> int {          // group -> caller, one group behind
+    HIPCHK(h, hipEventSynchronize(h->ev_out[st]));
+    const char* o = h->pin_out[st];
+    const size_t rows = (size_t)h->cap_rows;
+    if (p1) memcpy(p1 + s * 6, o, (size_t)nb * 24);
+    if (p2) memcpy(p2 + s * 5, o + rows * 24, (size_t)nb * 20);
+    if (a1) memcpy(a1 + s, o + rows * 44, (size_t)nb);
+    if (a2) memcpy(a2 + s, o + rows * 45, (size_t)nb);
     return NRV_OK;
   };
   int64_t g = 0, prev_s = 0;
   int prev_nb = 0;
   for (int64_t s = 0; s < n; s += h->batch, ++g) {
     const int st = (int)(g & 1);
-    int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
-    size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
+    const int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+    const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
     const float* hs = raw_reads ? nullptr : sig + (read_mode ? s * kSig : s * T * kSig);
     const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
-    if (!raw_reads) HIPCHK(h, hipMemcpyAsync(h->d_sig[st], hs, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_feat[st], hf, ev * kFeat * 4, hipMemcpyHostToDevice, h->copy_stream));
+    if (g >= 2) {
+      // staging set st was last used by group g-2: its upload has left the bounce buffers, its kernels
+      // have read d_sig / d_feat (ev_done) and its results have left d_p / d_a (ev_out)
+      if (!direct_s || !direct_f) HIPCHK(h, hipEventSynchronize(h->ev_in[st]));
+      HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_done[st], 0));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_out[st], 0));
+    }
+    if (!raw_reads) {
+      const void* src = hs;
+      if (!direct_s) { memcpy(h->pin_sig[st], hs, ev * kSig * 4); src = h->pin_sig[st]; }
+      HIPCHK(h, hipMemcpyAsync(h->d_sig[st], src, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
+    }
+    {
+      const void* src = hf;
+      if (!direct_f) { memcpy(h->pin_feat[st], hf, ev * kFeat * 4); src = h->pin_feat[st]; }
+      HIPCHK(h, hipMemcpyAsync(h->d_feat[st], src, ev * kFeat * 4, hipMemcpyHostToDevice, h->copy_stream));
+    }
     HIPCHK(h, hipEventRecord(h->ev_in[st], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[st], 0));
     if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[st]);
@@ -903,12 +986,23 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
                    h->d_a[st][0], h->d_a[st][1]);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev_done[st], h->stream));
-    if (g >= 1 && (rc = download(prev_s, prev_nb, st ^ 1))) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, h->ev_done[st], 0));
+    {
+      char* o = h->pin_out[st];
+      const size_t rows = (size_t)h->cap_rows;
+      if (p1) HIPCHK(h, hipMemcpyAsync(o, h->d_p[st][0], (size_t)nb * 24, hipMemcpyDeviceToHost, h->d2h_stream));
+      if (p2) HIPCHK(h, hipMemcpyAsync(o + rows * 24, h->d_p[st][1], (size_t)nb * 20, hipMemcpyDeviceToHost, h->d2h_stream));
+      if (a1) HIPCHK(h, hipMemcpyAsync(o + rows * 44, h->d_a[st][0], (size_t)nb, hipMemcpyDeviceToHost, h->d2h_stream));
+      if (a2) HIPCHK(h, hipMemcpyAsync(o + rows * 45, h->d_a[st][1], (size_t)nb, hipMemcpyDeviceToHost, h->d2h_stream));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_out[st], h->d2h_stream));
+    if (g >= 1 && (rc = finalize(prev_s, prev_nb, st ^ 1))) return rc;
     prev_s = s;
     prev_nb = nb;
   }
-  if (g >= 1 && (rc = download(prev_s, prev_nb, (int)((g - 1) & 1)))) return rc;
+  if ((rc = finalize(prev_s, prev_nb, (int)((g - 1) & 1)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+  HIPCHK(h, hipStreamSynchronize(h->d2h_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return NRV_OK;
 }

@@ -87,6 +87,16 @@ struct ActView {
 };
 
 
+// Cross-lane exchange through LDS inside ONE wave (no workgroup barrier): the hardware completes a
+// wave's DS operations in order, but the compiler must be told that the stores of this lane and the
+// loads of data written by other lanes are ordered - otherwise it may legally reorder or forward them.
+// No instruction is emitted besides what the fences require at wavefront scope.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // tanh for the LSTM cell: 1 - 2/(2^(2x log2 e) + 1) on the hardware exp2/rcp (1 ulp each): five
 // instructions, no branch, exact limits at +-inf.  Absolute error <= ~1.5e-7 everywhere (for
 // |x| -> 0 the RELATIVE error grows, which is immaterial here: the argument is a 200-500-term f32

@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
       im[(u >> 2) * PLANE + acc_row(reg, lane) * 4 + (u & 3)] = __builtin_fmaxf(acc[nt][reg], 0.f);
   }
   // dense2: 128 -> 32 (the same wave wrote the image; DS operations of one wave complete in order)
+  wave_lds_fence();
   f32x16 a2 = splat16(P.d2bias[l31]);
   {
     const float* hp = im + half * PLANE + l31 * 4;
@@ -100,9 +101,11 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
       for (int j = 0; j < 4; ++j) a2 = mfma32(a[j], w2[kg][j], a2);
     }
   }
+  wave_lds_fence();                                       // dense2's reads of the image before it is overwritten
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg)
     im[(l31 >> 2) * PLANE + acc_row(reg, lane) * 4 + (l31 & 3)] = __builtin_fmaxf(a2[reg], 0.f);
+  wave_lds_fence();
   // main_out: 32 -> 6 (padded to 32 columns)
   f32x16 a3 = splat16(P.mobias[l31]);
   {

@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
       hb[(4 * q + reg) * 16 + c] = og * tanh_fast(cn);
     }
     // h_t[row c][4q..4q+3]: next step's A fragment (k-step k uses unit 4q+k) AND this lane's output
+    wave_lds_fence();                                     // other lanes' stores above -> this lane's load
     hprev = *(const f32x4*)(hb + c * 16 + 4 * q);
+    wave_lds_fence();                                     // ... and this load before the next step's stores
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = hprev[k] * bsc[k] + bsh[k];

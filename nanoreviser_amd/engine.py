@@ -56,6 +56,42 @@ class _ReadDesc(C.Structure):
 _lib = None
 
 
+def _one_hip_runtime() -> str:
+    """One HIP runtime per process, without importing torch.
+
+    PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7, with its own HSA runtime
+    next to it); libnanorev_hip.so needs the same SONAME and would otherwise resolve it to /opt/rocm's.
+    Two HIP/HSA runtimes in one process do not share the GPU (the second sees no device), so whichever
+    copy a process is going to use must be the one that is mapped FIRST:
+      * a libamdhip64 is already mapped (torch was imported, or the caller linked HIP): nothing to do,
+        the dynamic linker resolves our NEEDED entry to it by SONAME;
+      * else, if torch is installed (found on sys.path, NOT imported), its bundled runtime is mapped
+        now (RTLD_GLOBAL), so a later `import torch` in this process finds its own copy already there;
+      * else (or NRV_NO_TORCH=1: a process that will never import torch, e.g. the command line) the
+        system runtime is found through the library's RUNPATH.
+    NRV_HIP_RUNTIME=/path/to/libamdhip64.so overrides all of it."""
+    try:
+        with open("/proc/self/maps") as fp:
+            if any("libamdhip64" in ln for ln in fp):
+                return "already mapped"
+    except OSError:
+        pass
+    cand = os.environ.get("NRV_HIP_RUNTIME")
+    if not cand and os.environ.get("NRV_NO_TORCH") != "1":
+        import importlib.util
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.origin:
+            c = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            cand = c if os.path.exists(c) else None
+    if cand:
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        return cand
+    return "system (RUNPATH)"
+
+
 def load_library(path: Optional[str] = None):
     """dlopen the engine.  Raises OSError loudly when it has not been built."""
     global _lib
@@ -65,15 +101,7 @@ def load_library(path: Optional[str] = None):
     if not os.path.exists(p):
         raise OSError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if ours
-    # (/opt/rocm) were loaded first and torch later, the process would hold two HSA runtimes and
-    # the second sees no GPU.  Importing torch first makes the dynamic linker resolve our
-    # NEEDED libamdhip64.so.7 to the copy torch already loaded.  (NRV_NO_TORCH=1 skips this.)
-    if os.environ.get("NRV_NO_TORCH") != "1":
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+    _one_hip_runtime()
     lib = C.CDLL(p)
     fp, i8p, vp = C.POINTER(C.c_float), C.POINTER(C.c_int8), C.c_void_p
     lib.nrv_create.argtypes = [C.POINTER(_Weights), C.POINTER(_Weights), C.c_int, C.c_int, C.c_int,

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nanoreviser_amd.engine import Reviser
 from nanoreviser_amd.weights import load_species
-from oracle import nrv_oracle as O
+from nanoreviser_amd import workload as O
 m1, m2 = load_species("ecoli")
 T = 13
 rv = Reviser(m1.with_window(T), m2.with_window(T))

@@ -1,10 +1,21 @@
 """Parity tests proper: the HIP path, called through the C-ABI (ctypes -> libnanorev_hip.so),
 against the oracle and the committed goldens.  MI355X only (-m gpu).
 
-Bars (BASELINE.json north_star): per-base argmax identical; softmax probabilities within 1e-4 of
-the fp64 arbiter for E. coli.  For the human weights the fp32 noise floor itself is 2.1e-4 (both
-independent f32 restatements of the oracle sit there on one window, tests/test_oracle.py), so the
-bound is 5e-4 there and the measured maxima are recorded in DESIGN.md.
+Bars (BASELINE.json north_star): per-base argmax identical; softmax probabilities within 1e-4 (fp32).
+How they are asserted, per window, against the fp64 arbiter AND both f32 restatements of the oracle:
+
+  * BAR = 1e-4 for both species.  A window is WELL-CONDITIONED when the oracle's own two f32
+    implementations (NumPy-f32 and the C port) both stay within BAR/2 of fp64 on it; on those the
+    engine must be within BAR of fp64, no exceptions.
+  * On the remaining, ILL-CONDITIONED windows fp32 arithmetic itself cannot hold the bar (the human
+    model2 has windows where both f32 restatements sit 2.1e-4 from fp64: SURVEY.md App. B,
+    tests/test_oracle.py); there the engine must be no worse than 3x the f32 restatements' own
+    deviation, and such windows must be rare (<= 1 %).  Their count and the maxima are printed and
+    recorded in DESIGN.md 5.
+  * argmax must equal the fp64 arbiter's.  The only tolerated difference is a NEAR-TIE: the arbiter's
+    top-2 margin on that window is below twice the measured f32 deviation of that window (floor
+    1e-6), i.e. fp32 arithmetic does not determine the call.  Near-ties are counted and the count is
+    asserted (0 on every real read; the synthetic T=13 set holds one window with margin 1.5e-6).
 """
 import numpy as np
 import pytest
@@ -13,24 +24,49 @@ from nanoreviser_amd import hoststage as hs
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"ecoli": 1e-4, "human": 5e-4}
+BAR = 1e-4
+MODES = ["bf16x3", "f32"]
 
 
-def assert_argmax(a, p_ref64, tol, what=""):
-    """argmax must equal the fp64 arbiter's, except on NEAR-TIES: windows where the arbiter's own
-    top-1 and the class the engine chose differ by <= 2*tol in probability, i.e. both calls are
-    correct to within the probability tolerance (minimum top-1/top-2 margins of
-    1.5e-4 occur with the human weights; the T=13 synthetic golden set holds one at 1.5e-6).
-    Returns the number of near-tie windows."""
-    ref = p_ref64.argmax(-1)
-    bad = np.nonzero(np.asarray(a) != ref)[0]
+def f32_floor(m1, m2, sig, rd, p64_1, p64_2, T=11, numpy_too=True):
+    """Per-window deviation of the oracle's OWN f32 implementations from the fp64 arbiter:
+    (nf1[n], nf2[n]) = max over classes and over {C port, NumPy-f32}."""
+    from oracle import c_oracle as CO
+    from oracle import nrv_oracle as O
+    c1, _ = CO.predict(m1.flat(), T, 6, sig, rd, threads=8)
+    c2, _ = CO.predict(m2.flat(), T, 5, sig, rd, threads=8)
+    nf1, nf2 = np.abs(c1 - p64_1).max(-1), np.abs(c2 - p64_2).max(-1)
+    if numpy_too:
+        q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sig, rd, np.float32)
+        nf1 = np.maximum(nf1, np.abs(q1 - p64_1).max(-1))
+        nf2 = np.maximum(nf2, np.abs(q2 - p64_2).max(-1))
+    return nf1, nf2
+
+
+def check_vs_fp64(p, a, p64, nf, what=""):
+    """The policy of the module docstring for one model's outputs.  Returns a dict of what was seen."""
+    p, a, p64 = np.asarray(p), np.asarray(a), np.asarray(p64)
+    err = np.abs(p - p64).max(-1)
+    well = nf <= BAR / 2
+    assert (err[well] <= BAR).all(), f"{what}: well-conditioned window off by {err[well].max():.2e}"
+    ill = ~well
+    if ill.any():
+        assert (err[ill] <= 3 * nf[ill]).all(), \
+            f"{what}: ill-conditioned window off by {err[ill].max():.2e} (f32 floor there {nf[ill].max():.2e})"
+    assert ill.mean() <= 0.01, f"{what}: {ill.sum()} of {len(ill)} windows ill-conditioned"
+    ref = p64.argmax(-1)
+    bad = np.nonzero(a != ref)[0]
+    srt = np.sort(p64, -1)
+    margin = srt[:, -1] - srt[:, -2]
     for i in bad:
-        gap = p_ref64[i, ref[i]] - p_ref64[i, int(a[i])]
-        assert gap <= 2 * tol, f"{what}: window {i}: engine class {int(a[i])} vs {ref[i]}, fp64 gap {gap:.2e}"
-    return len(bad)
+        assert margin[i] <= 2 * max(nf[i], 1e-6), \
+            f"{what}: window {i}: engine class {int(a[i])} vs {ref[i]}, fp64 margin {margin[i]:.2e}, f32 floor {nf[i]:.2e}"
+    return {"max_err": float(err.max()), "max_err_well": float(err[well].max()) if well.any() else 0.0,
+            "ill": int(ill.sum()), "near_ties": int(len(bad)), "n": int(len(err)),
+            "max_f32_floor": float(nf.max())}
 
 
-@pytest.fixture(scope="module", params=["bf16x3", "f32"], autouse=True)
+@pytest.fixture(scope="module", params=MODES, autouse=True)
 def precision(request):
     """Every test of this module runs once per matrix-arithmetic mode (include/nanorev.h
     nrv_set_precision); NRV_PRECISION is what a new handle starts in.  Same bars for both."""
@@ -64,38 +100,104 @@ def _windows(reads, key, T=11):
 
 
 @pytest.mark.parametrize("sp", ["ecoli", "human"])
-def test_fixture_reads_vs_committed_fp64_goldens(engines, reads, model_goldens, sp):
+def test_fixture_reads_vs_committed_fp64_goldens(engines, reads, model_goldens, species_models, sp, precision):
     rv = engines[sp]
-    worst, ties = 0.0, 0
+    m1, m2 = species_models[sp]
+    tot = {"max_err": 0.0, "max_err_well": 0.0, "ill": 0, "near_ties": 0, "n": 0, "max_f32_floor": 0.0}
     for key in reads.keys:
         _, sw, fw = _windows(reads, key)
         idx = model_goldens[f"{key}/idx"]
-        p1, p2, a1, a2 = rv.predict_pair(np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx]))
-        d1 = np.abs(p1 - model_goldens[f"{key}/{sp}/p1"]).max()
-        d2 = np.abs(p2 - model_goldens[f"{key}/{sp}/p2"]).max()
-        worst = max(worst, d1, d2)
-        ties += assert_argmax(a1, model_goldens[f"{key}/{sp}/p1"], TOL[sp], key)
-        ties += assert_argmax(a2, model_goldens[f"{key}/{sp}/p2"], TOL[sp], key)
-        assert d1 <= TOL[sp] and d2 <= TOL[sp], (key, d1, d2)
-    if sp == "ecoli":
-        assert ties == 0
-    print(f"{sp}: near-tie argmax windows: {ties}")
-    print(f"{sp}: max |dp| vs fp64 goldens over 5 reads x 384 windows = {worst:.2e}")
+        sig, rd = np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx])
+        g1, g2 = model_goldens[f"{key}/{sp}/p1"], model_goldens[f"{key}/{sp}/p2"]
+        p1, p2, a1, a2 = rv.predict_pair(sig, rd)
+        nf1, nf2 = f32_floor(m1, m2, sig, rd, g1, g2)
+        for r in (check_vs_fp64(p1, a1, g1, nf1, f"{sp} {key} m1"), check_vs_fp64(p2, a2, g2, nf2, f"{sp} {key} m2")):
+            for k in tot:
+                tot[k] = max(tot[k], r[k]) if k.startswith("max") else tot[k] + r[k]
+    assert tot["near_ties"] == 0                           # real reads: every call is the arbiter's
+    print(f"PARITY {precision} {sp}: {tot}")
 
 
 @pytest.mark.parametrize("sp", ["ecoli", "human"])
-def test_synthetic_goldens_T11_and_T13(species_models, model_goldens, sp):
+def test_synthetic_goldens_T11_and_T13(species_models, model_goldens, sp, precision):
     from nanoreviser_amd.engine import Reviser
     m1, m2 = species_models[sp]
+    ties = 0
     for T in (11, 13):
-        rv = Reviser(m1.with_window(T), m2.with_window(T))
+        a, b = m1.with_window(T), m2.with_window(T)
+        rv = Reviser(a, b)
         sig, rd = model_goldens[f"synth{T}/signal"], model_goldens[f"synth{T}/read"]
+        g1, g2 = model_goldens[f"synth{T}/{sp}/p1"], model_goldens[f"synth{T}/{sp}/p2"]
         p1, p2, a1, a2 = rv.predict_pair(sig, rd)
-        assert_argmax(a1, model_goldens[f"synth{T}/{sp}/p1"], TOL[sp], f"synth{T} m1")
-        assert_argmax(a2, model_goldens[f"synth{T}/{sp}/p2"], TOL[sp], f"synth{T} m2")
-        assert np.abs(p1 - model_goldens[f"synth{T}/{sp}/p1"]).max() <= TOL[sp]
-        assert np.abs(p2 - model_goldens[f"synth{T}/{sp}/p2"]).max() <= TOL[sp]
+        nf1, nf2 = f32_floor(a, b, sig, rd, g1, g2, T)
+        ties += check_vs_fp64(p1, a1, g1, nf1, f"synth{T} {sp} m1")["near_ties"]
+        ties += check_vs_fp64(p2, a2, g2, nf2, f"synth{T} {sp} m2")["near_ties"]
         rv.close()
+    assert ties <= 1                                       # synth13 holds one window with an fp64 margin of 1.5e-6
+    print(f"PARITY {precision} {sp} synthetic: near-ties {ties}")
+
+
+@pytest.mark.parametrize("sp", ["ecoli", "human"])
+def test_whole_reads_vs_both_f32_restatements(engines, reads, species_models, sp, precision):
+    """Every window of two whole fixture reads (15.4 k windows) per species: the engine against the
+    reference-shaped f32 arithmetic (C port; NumPy-f32 on a slice).  Two correct f32 evaluations of
+    the same graph differ by at most the sum of their rounding noises: <= BAR on every window where
+    the graph is well-conditioned, identical calls outside fp32 near-ties."""
+    from oracle import c_oracle as CO
+    from oracle import nrv_oracle as O
+    rv = engines[sp]
+    m1, m2 = species_models[sp]
+    worst_c, worst_np, n_over, n_mis, n_all = 0.0, 0.0, 0, 0, 0
+    for key in ("ch117_read6465", "ch13_read2251"):
+        _, sw, fw = _windows(reads, key)
+        sw, fw = np.ascontiguousarray(sw), np.ascontiguousarray(fw)
+        p1, p2, a1, a2 = rv.predict_pair(sw, fw)
+        c1, ca1 = CO.predict(m1.flat(), 11, 6, sw, fw, threads=8)
+        c2, ca2 = CO.predict(m2.flat(), 11, 5, sw, fw, threads=8)
+        d = np.maximum(np.abs(p1 - c1).max(-1), np.abs(p2 - c2).max(-1))
+        worst_c = max(worst_c, float(d.max()))
+        n_over += int((d > BAR).sum())
+        n_all += len(d)
+        for a, ca, c in ((a1, ca1, c1), (a2, ca2, c2)):
+            for i in np.nonzero(a != ca)[0]:
+                srt = np.sort(c[i])
+                assert srt[-1] - srt[-2] <= 2 * BAR, (key, int(i))    # only where f32 itself cannot decide
+                n_mis += 1
+        sl = slice(1000, 1400)
+        q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sw[sl], fw[sl], np.float32)
+        worst_np = max(worst_np, float(np.abs(p1[sl] - q1).max()), float(np.abs(p2[sl] - q2).max()))
+    print(f"PARITY {precision} {sp} whole reads: max|dp| vs C-f32 {worst_c:.2e} ({n_over} of {n_all} windows > 1e-4), "
+          f"vs NumPy-f32 {worst_np:.2e}, argmax differences vs C-f32 {n_mis}")
+    assert n_over <= 0.001 * n_all and worst_c <= 5 * BAR and worst_np <= 2 * BAR
+    assert n_mis <= 2
+    if sp == "ecoli":
+        assert worst_c <= BAR and n_mis == 0
+
+
+@pytest.mark.parametrize("sp,batch", [("ecoli", 512), ("human", 4096)])
+def test_config_batch_sizes_C2_C3(reads, species_models, sp, batch):
+    """BASELINE configs[1] (ecoli, batch=512 windows) and configs[2] (human, batch=4096) on whole
+    fixture reads through the host entry points: same bits as any other grouping, checked against the
+    C-f32 oracle."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import c_oracle as CO
+    m1, m2 = species_models[sp]
+    rt, sw, fw = _windows(reads, "ch141_read5436")
+    sw, fw = np.ascontiguousarray(sw), np.ascontiguousarray(fw)
+    rv = Reviser(m1, m2, batch=batch)
+    assert rv.batch == batch
+    p1, p2, a1, a2 = rv.predict_pair(sw, fw)
+    r = rv.predict_read(rt.sig_ev, rt.feat_ev)
+    rv.close()
+    rv = Reviser(m1, m2, batch=1000)
+    o = rv.predict_pair(sw, fw)
+    rv.close()
+    for x, y, z in zip((p1, p2, a1, a2), r, o):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    c1, ca1 = CO.predict(m1.flat(), 11, 6, sw, fw, threads=8)
+    c2, ca2 = CO.predict(m2.flat(), 11, 5, sw, fw, threads=8)
+    assert np.abs(p1 - c1).max() <= 2 * BAR and np.abs(p2 - c2).max() <= 2 * BAR
+    assert (a1 != ca1).sum() + (a2 != ca2).sum() <= 1
 
 
 def test_whole_read_live_oracle_and_read_mode(engines, reads, species_models):
@@ -203,15 +305,17 @@ def test_extreme_inputs_stay_finite(engines):
     assert np.array_equal(a1, p1.argmax(-1)) and np.array_equal(a2, p2.argmax(-1))
 
 
-def test_full_size_properties_device_api(species_models):
+@pytest.mark.parametrize("sp", ["ecoli", "human"])
+def test_full_size_properties_device_api(species_models, sp):
     """BASELINE sizes through the device-pointer entry points: 1 M synthetic 13-event windows in
     groups of 4096 (configs[3]) and one 200 k-event read (configs[4]).  Size-independent properties:
     determinism, permutation equivariance (rows independent), batch-grouping invariance,
     probabilities sum to 1, argmax == argmax(prob), read mode == window mode."""
     import torch
     from nanoreviser_amd.engine import Reviser
-    m1, m2 = species_models["ecoli"]
-    T, n = 13, 1 << 20
+    from oracle import c_oracle as CO
+    m1, m2 = species_models[sp]
+    T, n = 13, (1 << 20) if sp == "ecoli" else (1 << 17)     # configs[3] is the E. coli one
     rv = Reviser(m1.with_window(T), m2.with_window(T), batch=4096)
     # device-pointer calls are asynchronous on the handle's stream, which is ordered after the
     # default stream torch produces these inputs on
@@ -264,6 +368,15 @@ def test_full_size_properties_device_api(species_models):
         w = run(sig_ev[idx + base].contiguous(), feat_ev[idx + base].contiguous(), rv)
         assert torch.equal(w[0], p1[base:base + 20_000]) and torch.equal(w[1], p2[base:base + 20_000])
         assert torch.equal(w[2], a1[base:base + 20_000]) and torch.equal(w[3], a2[base:base + 20_000])
+    # and the streamed read against the C-f32 oracle's own read mode on a slice from its middle
+    lo, cnt = 150_000, 3000
+    se, fe = sig_ev[lo:lo + cnt + T].cpu().numpy(), feat_ev[lo:lo + cnt + T].cpu().numpy()
+    a, b = m1.with_window(T), m2.with_window(T)
+    c1, ca1 = CO.predict_read(a.flat(), T, 6, se, fe, threads=8)
+    c2, ca2 = CO.predict_read(b.flat(), T, 5, se, fe, threads=8)
+    assert np.abs(p1[lo:lo + cnt].cpu().numpy() - c1).max() <= 2 * BAR
+    assert np.abs(p2[lo:lo + cnt].cpu().numpy() - c2).max() <= 2 * BAR
+    assert (a1[lo:lo + cnt].cpu().numpy() != ca1).sum() + (a2[lo:lo + cnt].cpu().numpy() != ca2).sum() <= 2
     rv.close()
 
 
@@ -281,9 +394,9 @@ def test_other_window_lengths_vs_oracle(species_models, T):
     rv = Reviser(a, b)
     p1, p2, a1, a2 = rv.predict_pair(sig, rd)
     q1, q2, _, _ = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float64)
-    assert np.abs(p1 - q1).max() <= 1e-4 and np.abs(p2 - q2).max() <= 1e-4
-    assert_argmax(a1, q1, 1e-4, f"T={T} m1")
-    assert_argmax(a2, q2, 1e-4, f"T={T} m2")
+    nf1, nf2 = f32_floor(a, b, sig, rd, q1, q2, T)
+    check_vs_fp64(p1, a1, q1, nf1, f"T={T} m1")
+    check_vs_fp64(p2, a2, q2, nf2, f"T={T} m2")
     # read mode at this T
     N = 70 + T
     rng = np.random.default_rng(T)
