@@ -118,6 +118,7 @@ int nrv_get_batch(nrv_handle* h);
  * a new handle starts in. */
 #define NRV_PREC_F32 0
 #define NRV_PREC_BF16X3 1
+#define NRV_PREC_F16X2 2
 int nrv_set_precision(nrv_handle* h, int mode);
 int nrv_get_precision(nrv_handle* h);
 

@@ -146,6 +146,79 @@ NRV_HOST_COLD static void pack_lstm_split(const Blob& b, int base, int Kin, int 
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
+// ---- f16x2 packing (lstm_h2_kernel, nrv_lstm_f16x2.h) ------------------------------------------------
+// largest s with bound * 2^s <= 2^14 (f16 overflows at 65504: two binades of head-room)
+static int pow2_room(float bound) {
+  if (!(bound > 0.f)) return 14;
+  int e;
+  (void)std::frexp(bound, &e);                    // bound = m 2^e, m in [0.5, 1)
+  return 14 - e;
+}
+static float max_abs(const float* p, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(p[i]));
+  return m;
+}
+// The layer's accumulator exponent E: every operand tensor t enters the matrix pipe as t * 2^(its
+// exponent), activations with their buffer's exponent s_in (fixed by the producer), weights with
+// E - s_in, so that all products of a layer carry the same 2^E and add up in one accumulator.  E is
+// the largest value that keeps every scaled weight block below 2^14.
+static int plan_exponent(const Blob& b, int base, int K0, int s0, int K1, int s1, int H) {
+  int E = 1 << 20;
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);
+    const float* U = b.t(base + dir * 3 + 1);
+    E = std::min(E, s0 + pow2_room(max_abs(W, (size_t)K0 * 4 * H)));
+    if (K1) E = std::min(E, s1 + pow2_room(max_abs(W + (size_t)K0 * 4 * H, (size_t)K1 * 4 * H)));
+    E = std::min(E, 13 + pow2_room(max_abs(U, (size_t)H * 4 * H)));
+  }
+  return E;
+}
+static inline void split_f16(float v, uint16_t* hi, uint16_t* lo) {
+  const _Float16 h = (_Float16)v;                 // round to nearest even
+  const _Float16 l = (_Float16)(v - (float)h);
+  memcpy(hi, &h, 2);
+  memcpy(lo, &l, 2);
+}
+// [dir][hg][kb][gate][term 2][64 lanes][8 f16]; lane l holds k = 16*kb + 8*(l>>5) + j, column (gate,
+// unit hg*32 + (l&31)); input rows k < K0 are scaled by 2^(E - s0), k >= K0 by 2^(E - s1), recurrent
+// rows by 2^(E - 13).  bias [dir][hg][gate][32] x 2^E.
+NRV_HOST_COLD static void pack_lstm_h2(const Blob& b, int base, int K0, int s0, int K1, int s1, int H, int E,
+                                       std::vector<float>& out, std::vector<float>& bias) {
+  const int Kin = K0 + K1;
+  const int NG = (H + 31) / 32, KB_IN = Kin / 16, KB = KB_IN + H / 16;
+  std::vector<uint16_t> w((size_t)2 * NG * KB * 4 * 2 * 64 * 8, 0);
+  bias.assign((size_t)2 * NG * 4 * 32, 0.f);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);
+    const float* U = b.t(base + dir * 3 + 1);
+    const float* B = b.t(base + dir * 3 + 2);
+    for (int hg = 0; hg < NG; ++hg) {
+      for (int kb = 0; kb < KB; ++kb)
+        for (int g = 0; g < 4; ++g)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int unit = hg * 32 + (lane & 31);
+              float v = 0.f;
+              if (unit < H) {
+                const int k = 16 * (kb < KB_IN ? kb : kb - KB_IN) + 8 * (lane >> 5) + j;
+                if (kb < KB_IN) v = std::ldexp(W[(size_t)k * 4 * H + g * H + unit], E - (k < K0 ? s0 : s1));
+                else v = std::ldexp(U[(size_t)k * 4 * H + g * H + unit], E - 13);
+              }
+              const size_t o = (((((size_t)(dir * NG + hg) * KB + kb) * 4 + g) * 2) * 64 + lane) * 8 + j;
+              split_f16(v, &w[o], &w[o + 64 * 8]);
+            }
+      for (int g = 0; g < 4; ++g)
+        for (int c = 0; c < 32; ++c) {
+          const int unit = hg * 32 + c;
+          bias[((size_t)(dir * NG + hg) * 4 + g) * 32 + c] = unit < H ? std::ldexp(B[g * H + unit], E) : 0.f;
+        }
+    }
+  }
+  out.assign((w.size() + 1) / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+}
+
 // head_mlp_split_kernel: the three per-timestep dense layers as A operands of the transposed
 // product, 126 fragments [64 lanes][8 bf16] (x3 terms): lane l, element j of a fragment hold
 // W[f][n] with n = 32*mt + (l&31) and f the input feature that the B operand carries in slot
@@ -188,13 +261,13 @@ NRV_HOST_COLD static void pack_head_split(const Blob& b, std::vector<float>& out
 
 // cnn_kernel<true>: dense 400->64 as split-bf16 B fragments [kb 25][nh 2][term 3][64 lanes][8 bf16];
 // lane l, element j hold W[k][n] with k = 16*kb + 8*(l>>5) + j (flatten index p*8+o), n = 32*nh + (l&31).
-NRV_HOST_COLD static void pack_cnn_split(const float* W, std::vector<float>& out) {
+NRV_HOST_COLD static void pack_cnn_split(const float* W, std::vector<float>& out, int sexp = 0) {
   std::vector<uint16_t> w((size_t)25 * 2 * 3 * 512, 0);
   for (int kb = 0; kb < 25; ++kb)
     for (int nh = 0; nh < 2; ++nh)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-          float rem = W[(size_t)(16 * kb + 8 * (lane >> 5) + j) * 64 + 32 * nh + (lane & 31)];
+          float rem = std::ldexp(W[(size_t)(16 * kb + 8 * (lane >> 5) + j) * 64 + 32 * nh + (lane & 31)], sexp);
           for (int tm = 0; tm < 3; ++tm) {
             const uint16_t q = f32_to_bf16_rne(rem);
             rem -= bf16_to_f32_host(q);
@@ -280,6 +353,11 @@ struct DevModel {
   size_t l_ws[4];             // lstm2..4 weights split into three bf16 terms (index 1..3)
   size_t d1p, d1b, d2p, d2b, mop, mob, fw, fb, ow, ob;
   size_t h_ws, h_wb;          // head_mlp_split_kernel: split weights / biases
+  // f16x2 mode (nrv_lstm_f16x2.h): lstm2..4 weights as two f16 terms, scaled biases, output scale /
+  // shift with the buffer exponents folded in, the producers' scaled epilogue constants
+  size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
+  float descale[4];
+  size_t l1s2, l1h2, dsplit2, dbias2;
   int C;
 };
 
@@ -312,6 +390,8 @@ struct nrv_handle {
   SegRead* d_reads = nullptr;
   size_t cap_raw = 0, cap_starts = 0, cap_reads = 0;
   hipEvent_t ev_raw = nullptr;
+  int h2 = 0;                      // 1: f16x2 mode - lstm2..4 on lstm_h2_kernel, activations between the kernels
+                                   // as f16 split planes (cnn dense and head stay on their bf16x3 kernels)
   int split = 62;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers, 5 = signal-branch
                                    // dense) runs its split-bf16 kernel (nrv_set_precision: BF16X3 = 62, F32 = 0)
   int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (tuned on MI355X at 4096 windows)
@@ -381,6 +461,49 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
   for (int l = 1; l < 4; ++l) {
     pack_lstm_split(b, lbase[l], lK[l], lH[l], wp);
     d.l_ws[l] = put(wp.data(), wp.size());
+  }
+  {
+    // f16x2 plan.  Buffer exponents: BatchNorm'd LSTM outputs are bounded by |scale| + |shift| per
+    // channel (|h| < 1); the signal branch's output has no static bound: 2^6 (|S| <= 92 on the fixture
+    // reads; the producer clamps at +-60000 / 2^6).
+    auto bn_exp = [&](int bnb, int n, std::vector<float>& sc, std::vector<float>& sh) {
+      sc.assign(n, 1.f); sh.assign(n, 0.f);
+      bn_fold(b.t(bnb), b.t(bnb + 1), b.t(bnb + 2), b.t(bnb + 3), n, sc.data(), sh.data());
+      float bound = 0.f;
+      for (int i = 0; i < n; ++i) bound = std::fmax(bound, std::fabs(sc[i]) + std::fabs(sh[i]));
+      return pow2_room(bound);
+    };
+    std::vector<float> sc1, sh1, sc2, sh2, sc3, sh3;
+    const int sX1 = bn_exp(18, 32, sc1, sh1), sX2 = bn_exp(28, 128, sc2, sh2), sX3 = bn_exp(40, 256, sc3, sh3);
+    const int sS = 6;
+    auto put_scaled = [&](const std::vector<float>& v, int e) {
+      std::vector<float> t(v.size());
+      for (size_t i = 0; i < v.size(); ++i) t[i] = std::ldexp(v[i], e);
+      return put(t.data(), t.size());
+    };
+    d.l1s2 = put_scaled(sc1, sX1);                       // lstm1 keeps h unscaled in its LDS image
+    d.l1h2 = put_scaled(sh1, sX1);
+    pack_cnn_split(b.t(32), wp, sS);
+    d.dsplit2 = put(wp.data(), wp.size());
+    {
+      std::vector<float> db(b.t(33), b.t(33) + 64);
+      d.dbias2 = put_scaled(db, sS);
+    }
+    const int K0[4] = {0, 32, 128, 256}, K1[4] = {0, 0, 64, 0}, s0[4] = {0, sX1, sX2, sX3}, s1[4] = {0, 0, sS, 0};
+    const std::vector<float>* osc[4] = {nullptr, &sc2, &sc3, nullptr};
+    const std::vector<float>* osh[4] = {nullptr, &sh2, &sh3, nullptr};
+    const int sout[4] = {0, sX2, sX3, 0};
+    for (int l = 1; l < 4; ++l) {
+      const int E = plan_exponent(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l]);
+      pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs);
+      d.l_w2[l] = put(wp.data(), wp.size());
+      d.l_b2[l] = put(bs.data(), bs.size());
+      d.descale[l] = std::ldexp(1.f, -E);
+      // the LDS image holds h * 2^13: scale' = scale * 2^(s_out - 13), shift' = shift * 2^s_out
+      std::vector<float> one(2 * lH[l], 1.f), zero(2 * lH[l], 0.f);
+      d.l_s2[l] = put_scaled(osc[l] ? *osc[l] : one, sout[l] - 13);
+      d.l_h2[l] = put_scaled(osh[l] ? *osh[l] : zero, sout[l]);
+    }
   }
   pack_lstm1_16(b, 12, wp, bs);
   d.l1w16 = put(wp.data(), wp.size());
@@ -517,6 +640,23 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
 }
 
+template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA>
+static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
+                           float* const out[2], int T, int n, int tiles) {
+  constexpr int NG = (H + 31) / 32;
+  LstmH2Args sa;
+  sa.T = T; sa.n_rows = n;
+  for (int m = 0; m < 2; ++m) {
+    const DevModel& d = h->dm[m];
+    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2[layer], d.all + d.l_b2[layer], d.all + d.l_s2[layer],
+                                d.all + d.l_h2[layer], in0[m], in1[m], out[m], d.descale[layer]};
+  }
+  sa.n_blk = (tiles + R * WR - 1) / (R * WR);
+  dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+}
+
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
 // n + T - 1 events and the windows are formed on the device.
 static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int n, bool read_mode,
@@ -550,7 +690,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     CnnArgs a;
     for (int m = 0; m < 2; ++m) {
       const DevModel& d = h->dm[m];
-      a.m[m] = CnnModelParams{d.all + d.conv, d.all + d.dpack, d.all + d.dbias, d.all + d.dsplit, h->S[m]};
+      a.m[m] = CnnModelParams{d.all + d.conv, d.all + d.dpack, d.all + (h->h2 ? d.dbias2 : d.dbias),
+                              d.all + (h->h2 ? d.dsplit2 : d.dsplit), h->S[m]};
     }
     a.signal = d_sig;
     if (read_mode) { a.T = 1; a.n_rows = n + T - 1; }
@@ -558,7 +699,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     a.n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
     // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
     int blocks = a.n_tiles < 128 ? a.n_tiles : 128;
-    if (h->split & 32) hipLaunchKernelGGL(cnn_kernel<true>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+    if (h->h2) hipLaunchKernelGGL((cnn_kernel<true, true>), dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+    else if (h->split & 32) hipLaunchKernelGGL(cnn_kernel<true>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     else hipLaunchKernelGGL(cnn_kernel<false>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     if ((rc = mark(1))) return rc;
   }
@@ -572,18 +714,21 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[0], d.all + d.l_b[0], d.all + d.l_s[0], d.all + d.l_h[0],
                                ActView{}, ActView{}, d_feat, read_mode ? 1 : 0, h->X1[m]};
     }
-    if (h->geo[0] >= 0) {
+    if (h->geo[0] >= 0 && !h->h2) {
       launch_lstm<0, 0, 16, true>(h, a, tiles, h->geo[0]);
     } else {                                     // default: the dedicated 16x16x4 kernel
       Lstm1Args a1;
       a1.T = T; a1.n_rows = n;
       for (int m = 0; m < 2; ++m) {
         const DevModel& d = h->dm[m];
-        a1.m[m] = Lstm1ModelParams{d.all + d.l1w16, d.all + d.l1b16, d.all + d.l_s[0], d.all + d.l_h[0],
-                                   d_feat, read_mode ? 1 : 0, h->X1[m]};
+        a1.m[m] = Lstm1ModelParams{d.all + d.l1w16, d.all + d.l1b16, d.all + (h->h2 ? d.l1s2 : d.l_s[0]),
+                                   d.all + (h->h2 ? d.l1h2 : d.l_h[0]), d_feat, read_mode ? 1 : 0, h->X1[m]};
       }
       dim3 grid((n + 63) / 64, 2, 2);
-      if (h->act == 0) hipLaunchKernelGGL(lstm1_kernel<0>, grid, dim3(256), 0, h->stream, a1);
+      if (h->h2) {
+        if (h->act == 0) hipLaunchKernelGGL((lstm1_kernel<0, true>), grid, dim3(256), 0, h->stream, a1);
+        else hipLaunchKernelGGL((lstm1_kernel<1, true>), grid, dim3(256), 0, h->stream, a1);
+      } else if (h->act == 0) hipLaunchKernelGGL(lstm1_kernel<0>, grid, dim3(256), 0, h->stream, a1);
       else hipLaunchKernelGGL(lstm1_kernel<1>, grid, dim3(256), 0, h->stream, a1);
     }
     if ((rc = mark(2))) return rc;
@@ -592,7 +737,12 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[1], d.all + d.l_b[1], d.all + d.l_s[1], d.all + d.l_h[1],
                                win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
     }
-    if (h->split & 2) {
+    const ActView none[2] = {ActView{}, ActView{}};
+    if (h->h2) {
+      const ActView i0[2] = {win_view(h->X1[0], 8), win_view(h->X1[1], 8)};
+      float* const o[2] = {h->X2[0], h->X2[1]};
+      launch_lstm_h2<8, 0, 64, 1, 2, false, 1, 1>(h, 1, i0, none, o, T, n, tiles);
+    } else if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
       launch_lstm_split<8, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
@@ -605,7 +755,13 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[2], d.all + d.l_b[2], d.all + d.l_s[2], d.all + d.l_h[2],
                                win_view(h->X2[m], 32), sv, nullptr, 0, h->X3[m]};
     }
-    if (h->split & 4) {
+    if (h->h2) {
+      const ActView i0[2] = {win_view(h->X2[0], 32), win_view(h->X2[1], 32)};
+      const ActView i1[2] = {read_mode ? ActView{h->S[0], 16, 1, 1, 0} : win_view(h->S[0], 16),
+                             read_mode ? ActView{h->S[1], 16, 1, 1, 0} : win_view(h->S[1], 16)};
+      float* const o[2] = {h->X3[0], h->X3[1]};
+      launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3>(h, 2, i0, i1, o, T, n, tiles);
+    } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
     } else {
@@ -617,7 +773,11 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = LstmModelParams{d.all + d.l_w[3], d.all + d.l_b[3], d.all + d.l_s[3], d.all + d.l_h[3],
                                win_view(h->X3[m], 64), ActView{}, nullptr, 0, h->X2[m] /* X4 aliases X2 */};
     }
-    if (h->split & 8) {
+    if (h->h2) {
+      const ActView i0[2] = {win_view(h->X3[0], 64), win_view(h->X3[1], 64)};
+      float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2, f32 tiles for the head
+      launch_lstm_h2<64, 0, 64, 1, 2, true, 3, 3>(h, 3, i0, none, o, T, n, tiles);
+    } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
@@ -704,8 +864,9 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   if (!h) { g_create_error = "out of host memory"; return NRV_E_NOMEM; }
   h->device = device; h->T = T; h->act = recurrent_act;
   if (const char* s = getenv("NRV_PRECISION")) {                       // initial nrv_set_precision mode
-    if (!strcmp(s, "f32")) h->split = 0;
-    else if (!strcmp(s, "bf16x3")) h->split = 62;
+    if (!strcmp(s, "f32")) { h->split = 0; h->h2 = 0; }
+    else if (!strcmp(s, "bf16x3")) { h->split = 62; h->h2 = 0; }
+    else if (!strcmp(s, "f16x2")) { h->split = 62; h->h2 = 1; }
   }
   if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 62;   // tuning knob: per-layer mask
   if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
@@ -769,16 +930,17 @@ int nrv_get_batch(nrv_handle* h) { return h ? h->batch : NRV_E_INVALID; }
 int nrv_set_precision(nrv_handle* h, int mode) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (mode != NRV_PREC_F32 && mode != NRV_PREC_BF16X3) {
+  if (mode != NRV_PREC_F32 && mode != NRV_PREC_BF16X3 && mode != NRV_PREC_F16X2) {
     h->err = "nrv_set_precision: unknown mode";
     return NRV_E_INVALID;
   }
-  h->split = mode == NRV_PREC_BF16X3 ? 62 : 0;
+  h->split = mode == NRV_PREC_F32 ? 0 : 62;
+  h->h2 = mode == NRV_PREC_F16X2;
   return NRV_OK;
 }
 int nrv_get_precision(nrv_handle* h) {
   if (!h) return NRV_E_INVALID;
-  return h->split ? NRV_PREC_BF16X3 : NRV_PREC_F32;
+  return h->h2 ? NRV_PREC_F16X2 : (h->split ? NRV_PREC_BF16X3 : NRV_PREC_F32);
 }
 
 int nrv_set_stream(nrv_handle* h, void* s) {

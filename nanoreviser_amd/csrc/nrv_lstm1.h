@@ -20,7 +20,8 @@ struct Lstm1ModelParams {
   const float* bn_shift;  // [32]
   const float* plain_in;  // [n][T][6] (ev_stride 0) or [N][6] (ev_stride 1)
   int plain_ev_stride;
-  float* out;             // tiled window-major, KQ = 8: [tile32][T][8][32][4]
+  float* out;             // tiled window-major, KQ = 8: [tile32][T][8][32][4]; OUT_SPLIT: the same chunks as
+                          // f16 split planes [kb 2][term][half][32][8 f16] (nrv_lstm_f16x2.h), scale in bn_*
 };
 struct Lstm1Args {
   Lstm1ModelParams m[2];
@@ -28,7 +29,9 @@ struct Lstm1Args {
   int n_rows;
 };
 
-template <int ACT>
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int ACT, bool OUT_SPLIT = false>
 __global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
   __shared__ __attribute__((aligned(16))) float hbuf[4][16 * 16 + 16];
   const Lstm1ModelParams& P = args.m[blockIdx.z];
@@ -66,7 +69,11 @@ __global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
       if (q < 2) x1 = src[4 + q];                        // k = 4 + q    (k-step 1; k = 6,7 are padding)
     }
   };
-  float* out_base = P.out + ((size_t)(rb >> 1) * T * 8 + dir * 4 + q) * 128 + (16 * (rb & 1) + c) * 4;
+  // f32 tiles: chunk kq = dir*4 + q holds units 4q..4q+3 of this direction.  Split planes: the 16
+  // units of a direction are exactly k-block `dir`; units 4q..4q+3 are elements 4(q&1).. of half q>>1.
+  float* out_base = OUT_SPLIT
+      ? P.out + ((size_t)(rb >> 1) * T * 8 + dir * 4 + (q >> 1)) * 128 + (16 * (rb & 1) + c) * 4 + (q & 1) * 2
+      : P.out + ((size_t)(rb >> 1) * T * 8 + dir * 4 + q) * 128 + (16 * (rb & 1) + c) * 4;
 
   f32x4 cc = {0.f, 0.f, 0.f, 0.f};                       // cell state of (rows 4q+reg, unit c)
   f32x4 hprev = {0.f, 0.f, 0.f, 0.f};                    // h_{t-1}[row c][units 4q..4q+3]
@@ -109,7 +116,19 @@ __global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = hprev[k] * bsc[k] + bsh[k];
-    *(f32x4*)(out_base + (size_t)t * 8 * 128) = o;
+    if constexpr (OUT_SPLIT) {
+      f16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (_Float16)o[k];
+        lo[k] = (_Float16)(o[k] - (float)hi[k]);
+      }
+      float* d = out_base + (size_t)t * 8 * 128;
+      *(f16x4*)d = hi;                                    // term 0 (hi): chunk 4*kb + half
+      *(f16x4*)(d + 2 * 128) = lo;                        // term 1 (lo): chunk 4*kb + 2 + half
+    } else {
+      *(f32x4*)(out_base + (size_t)t * 8 * 128) = o;
+    }
     x0 = nx0; x1 = nx1;
   }
 }

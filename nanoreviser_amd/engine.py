@@ -35,7 +35,7 @@ SYMBOLS = [
     "nrv_device_count",
 ]
 
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x2": 2}
 
 
 class NrvError(RuntimeError):

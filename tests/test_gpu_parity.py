@@ -168,10 +168,12 @@ def test_whole_reads_vs_both_f32_restatements(engines, reads, species_models, sp
         worst_np = max(worst_np, float(np.abs(p1[sl] - q1).max()), float(np.abs(p2[sl] - q2).max()))
     print(f"PARITY {precision} {sp} whole reads: max|dp| vs C-f32 {worst_c:.2e} ({n_over} of {n_all} windows > 1e-4), "
           f"vs NumPy-f32 {worst_np:.2e}, argmax differences vs C-f32 {n_mis}")
-    assert n_over <= 0.001 * n_all and worst_c <= 5 * BAR and worst_np <= 2 * BAR
-    assert n_mis <= 2
-    if sp == "ecoli":
-        assert worst_c <= BAR and n_mis == 0
+    # two f32 evaluations differ by at most the sum of their own deviations from fp64 (measured over all
+    # 40 885 windows, profiles/r02a_precision_report.json: C port <= 8.5e-5 / 2.1e-4, engine <= 7.8e-5 /
+    # 1.8e-4 for E. coli / human), and almost never by more than the bar
+    assert n_over <= 0.001 * n_all and worst_np <= 2 * BAR
+    assert worst_c <= (2 * BAR if sp == "ecoli" else 5 * BAR)
+    assert n_mis <= (0 if sp == "ecoli" else 2)
 
 
 @pytest.mark.parametrize("sp,batch", [("ecoli", 512), ("human", 4096)])
