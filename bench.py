@@ -612,7 +612,7 @@ def run_rank(args):
             fl = flop_lstm3_launch(T, B, executed=True)
             ach = fl / avg_s / 1e12
             kname = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
-                     "f16x2": "lstm_h2_kernel<192,128>"}[args.precision]
+                     "f16x2": "lstm_h2o_kernel<32,16,128,2,1>"}[args.precision]
             out["roofline"] = {
                 "kernel": f"{kname} ({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak,
@@ -653,7 +653,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--window", type=int, default=13, help="events per window (T)")
     ap.add_argument("--species", default="ecoli")
-    ap.add_argument("--precision", default=os.environ.get("NRV_BENCH_PRECISION", "bf16x3"),
+    ap.add_argument("--precision", default=os.environ.get("NRV_BENCH_PRECISION", "f16x2"),
                     choices=sorted(PRODUCTS), help="matrix arithmetic (include/nanorev.h, nrv_set_precision)")
     ap.add_argument("--prime", type=int, default=300, help="untimed steps before the warm-up (clock settling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

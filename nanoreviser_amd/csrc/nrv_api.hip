@@ -390,7 +390,7 @@ struct nrv_handle {
   SegRead* d_reads = nullptr;
   size_t cap_raw = 0, cap_starts = 0, cap_reads = 0;
   hipEvent_t ev_raw = nullptr;
-  int h2 = 0;                      // 1: f16x2 mode - lstm2..4 on lstm_h2_kernel, activations between the kernels
+  int h2 = 1;                      // 1: f16x2 mode (the default) - lstm2..4 on lstm_h2_kernel, activations between the kernels
                                    // as f16 split planes (cnn dense and head stay on their bf16x3 kernels)
   int split = 62;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers, 5 = signal-branch
                                    // dense) runs its split-bf16 kernel (nrv_set_precision: BF16X3 = 62, F32 = 0)
@@ -640,7 +640,7 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA>
+template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA, int NBG, int NA>
 static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
                            float* const out[2], int T, int n, int tiles) {
   constexpr int NG = (H + 31) / 32;
@@ -653,8 +653,15 @@ static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], co
   }
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+  // NRV_H2V=1: the plain kernel (gates after the matrix phase) instead of the overlapped one
+  static const bool plain = getenv("NRV_H2V") && atoi(getenv("NRV_H2V")) == 1;
+  if (plain) {
+    if (h->act == 0) hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+    else hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+    return;
+  }
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA>), grid, blk, 0, h->stream, sa);
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -741,7 +748,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     if (h->h2) {
       const ActView i0[2] = {win_view(h->X1[0], 8), win_view(h->X1[1], 8)};
       float* const o[2] = {h->X2[0], h->X2[1]};
-      launch_lstm_h2<8, 0, 64, 1, 2, false, 1, 1>(h, 1, i0, none, o, T, n, tiles);
+      launch_lstm_h2<8, 0, 64, 1, 2, false, 1, 1, 8, 2>(h, 1, i0, none, o, T, n, tiles);
     } else if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
       launch_lstm_split<8, 0, 64, 1, 2>(h, a, ws, tiles);
@@ -760,7 +767,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       const ActView i1[2] = {read_mode ? ActView{h->S[0], 16, 1, 1, 0} : win_view(h->S[0], 16),
                              read_mode ? ActView{h->S[1], 16, 1, 1, 0} : win_view(h->S[1], 16)};
       float* const o[2] = {h->X3[0], h->X3[1]};
-      launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3>(h, 2, i0, i1, o, T, n, tiles);
+      launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3, 8, 4>(h, 2, i0, i1, o, T, n, tiles);
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
@@ -776,7 +783,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     if (h->h2) {
       const ActView i0[2] = {win_view(h->X3[0], 64), win_view(h->X3[1], 64)};
       float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2, f32 tiles for the head
-      launch_lstm_h2<64, 0, 64, 1, 2, true, 3, 3>(h, 3, i0, none, o, T, n, tiles);
+      launch_lstm_h2<64, 0, 64, 1, 2, true, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);

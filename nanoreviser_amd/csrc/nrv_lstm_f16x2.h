@@ -101,8 +101,14 @@ lstm_h2_kernel(const LstmH2Args args) {
   static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
   static_assert(LA <= KB_IN && LB <= KB_IN && LA >= 1 && LB >= 1, "leads must stay inside the input blocks");
 
+  // At R = 2 the weight and activation rings (LB = LA = 3) take 192 of the 256 VGPRs that VALU
+  // instructions can address; with the cell state (32 registers) on top hipcc spills, and a spill
+  // reload waits on vmcnt(0) - behind the whole prefetch queue.  The cell state then lives in LDS
+  // ([cell][thread]: conflict-free, 32 KB).
+  constexpr bool CLDS = R >= 2;
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
   __shared__ __attribute__((aligned(16))) float bnl[2 * H];
+  __shared__ float cl[CLDS ? 16 * R * NTHREADS : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,9 +137,14 @@ lstm_h2_kernel(const LstmH2Args args) {
     bnl[i] = i < H ? P.out_scale[dir * H + i] : P.out_shift[dir * H + i - H];
   __syncthreads();
 
-  f32x16 c[R];
+  f32x16 c[CLDS ? 1 : R];
+  if constexpr (CLDS) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+    for (int i = 0; i < 16 * R; ++i) cl[i * NTHREADS + threadIdx.x] = 0.f;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+  }
 
   // Input addressing of one timestep: per row tile a buffer resource and a lane offset per segment.
   struct ABase {
@@ -269,8 +280,12 @@ lstm_h2_kernel(const LstmH2Args args) {
           const float fg = gate_act_scaled<ACT>(acc[1][r][reg], dsc, dsc02);
           const float gg = tanh_fast_scaled(acc[2][r][reg], dsc2);
           const float og = gate_act_scaled<ACT>(acc[3][r][reg], dsc, dsc02);
-          const float cn = __builtin_fmaf(fg, c[r][reg], ig * gg);
-          c[r][reg] = cn;
+          float cprev;
+          if constexpr (CLDS) cprev = cl[(r * 16 + reg) * NTHREADS + threadIdx.x];
+          else cprev = c[r][reg];
+          const float cn = __builtin_fmaf(fg, cprev, ig * gg);
+          if constexpr (CLDS) cl[(r * 16 + reg) * NTHREADS + threadIdx.x] = cn;
+          else c[r][reg] = cn;
           hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = (og * tanh_fast(cn)) * kHScale;
           if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the accumulator read-out local
         }
@@ -327,6 +342,369 @@ lstm_h2_kernel(const LstmH2Args args) {
     const ABase nxt = mk_base(s + 1 < T ? (dir ? t - 1 : t + 1) : t);
     step(std::false_type{}, s, nxt);
     cur = nxt;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// lstm_h2o_kernel: lstm_h2_kernel with the VALU work of a step moved into the matrix shadow.
+//
+// PMC of lstm_h2_kernel (192->128, profiles/r02b_*): per step a wave spends 15.4 k cycles issuing its
+// 480 MFMAs and another ~8.6 k on ~1700 VALU instructions (gates, the split of h, BatchNorm + split of
+// the output) that run AFTER the matrix phase - the kernel's time is the SUM (matrix pipe 54 % busy).
+// Here the input blocks of step s+1, which do not depend on h_s, are issued while the VALU turns z_s
+// into (c_s, h_s), passes the barrier and writes h_s out:
+//     in(0)                                                  prologue
+//     rec(s):   Z += h_{s-1} U          recurrent blocks, the operand split in their own shadow
+//     in(s+1):  N  = b + x_{s+1} W      input blocks; between their MFMA groups: the gate elements of
+//                                       Z, then the barrier, then the copy-out items of h_s
+//     Z <-> N                           two accumulator sets, roles alternate: the body is unrolled x2
+// so that the serial section of a step is rec(s) alone.  The weight ring is kept per (k-block, gate)
+// entry (8 registers, NBG - 1 entries of lead) instead of per k-block: at R = 2 the two accumulator
+// sets take all 256 AGPRs and everything else must fit the 256 VGPRs.  The in() phase behind the last
+// step computes a product nobody reads (4.6 % of the 192->128 layer's MFMAs) and step 0's rec() runs
+// against a zeroed image (3 %): both keep the code to two bodies that fit the instruction cache.
+// ---------------------------------------------------------------------------------------
+template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int NBG, int NA>
+__global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
+lstm_h2o_kernel(const LstmH2Args args) {
+  constexpr int NG = (H + 31) / 32;
+  constexpr int KB0 = KQ0 / 4, KB1 = KQ1 / 4, KB_IN = KB0 + KB1, KB_REC = H / 16, KB = KB_IN + KB_REC;
+  constexpr int ROWS = 32 * R * WR;
+  constexpr int PLANE = ROWS * 4 + 4;
+  constexpr int HBUF = (NG * 32 / 4) * PLANE;
+  constexpr int NTHREADS = 64 * NG * WR;
+  constexpr int LBG = NBG - 1, LA = NA - 1;
+  static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
+  static_assert((4 * KB) % NBG == 0 && (4 * KB_IN) % NBG == 0 && KB % NA == 0 && KB_IN % NA == 0,
+                "ring sizes must divide the block counts");
+  static_assert(LA >= 1 && LA <= KB_IN && LA <= KB_REC && LBG <= 4 * KB_REC, "leads must stay inside a phase");
+
+  constexpr bool CLDS = R >= 2;
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
+  __shared__ __attribute__((aligned(16))) float bnl[2 * H];
+  __shared__ float cl[CLDS ? 16 * R * NTHREADS : 1];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hg = wave % NG, wr = wave / NG;
+  const int half = lane >> 5, l31 = lane & 31;
+  const LstmBlock blk = lstm_block();
+  if (blk.rowblk >= args.n_blk) return;
+  const int dir = blk.dir;
+  const LstmH2ModelParams& P = args.m[blk.model];
+  const int T = args.T;
+  const int row0 = blk.rowblk * ROWS + wr * (32 * R);
+  const int lrow0 = wr * (32 * R);
+
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(
+      (const char*)P.wsplit + ((size_t)(dir * NG + hg) * KB) * (4 * 2 * 1024), KB * 4 * 2 * 1024);
+  const unsigned wlane = lane * 16;
+  const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * 32 + l31;
+  // The bias (x 2^E in memory) is not added to the accumulators - a pre-splatted 16-register tile per
+  // gate would sit in the register file for the whole launch - it rides on the gate constants:
+  //   hard_sigmoid(z) = clamp(acc * 0.2d + (0.5 + 0.2 b)),  tanh(z) from exp2(acc * 2log2e d + 2log2e b)
+  const float dsc = P.descale, dsc02 = 0.2f * dsc, dsc2 = 2.885390081777927f * dsc;
+  const float bz[4] = {bp[0] * dsc, bp[32] * dsc, bp[64] * dsc, bp[96] * dsc};      // exact: d is a power of two
+  const float kI = __builtin_fmaf(bz[0], 0.2f, 0.5f), kF = __builtin_fmaf(bz[1], 0.2f, 0.5f),
+              kO = __builtin_fmaf(bz[3], 0.2f, 0.5f), kG = bz[2] * 2.885390081777927f;
+  const int u = hg * 32 + l31;
+  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half) * 4;
+  const int hp_off = (2 * half) * PLANE + (lrow0 + l31) * 4;
+
+  for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
+    bnl[i] = i < H ? P.out_scale[dir * H + i] : P.out_shift[dir * H + i - H];
+  for (int i = threadIdx.x; i < HBUF; i += NTHREADS) hbuf[i] = 0.f;          // image of h_{-1} (buffer 0)
+  f32x16 c[CLDS ? 1 : R];
+  if constexpr (CLDS) {
+#pragma unroll
+    for (int i = 0; i < 16 * R; ++i) cl[i * NTHREADS + threadIdx.x] = 0.f;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+  }
+  __syncthreads();
+
+  struct ABase {
+    __amdgpu_buffer_rsrc_t r0[R], r1[R];
+    unsigned v0[R], v1[R];
+  };
+  auto mk_base = [&](int s) __attribute__((always_inline)) {
+    const int sc = s < T ? s : T - 1;                    // a step past the end aliases the last one (unused product)
+    const int t = dir ? (T - 1 - sc) : sc;
+    ABase ab;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ab.r0[r] = make_rsrc(P.in0.ubase(row0 + r * 32, t), 0xffffffffu);
+      ab.v0[r] = P.in0.voff(row0 + r * 32, t, l31, half) * 4;
+      if constexpr (KQ1 > 0) {
+        ab.r1[r] = make_rsrc(P.in1.ubase(row0 + r * 32, t), 0xffffffffu);
+        ab.v1[r] = P.in1.voff(row0 + r * 32, t, l31, half) * 4;
+      } else {
+        ab.r1[r] = ab.r0[r];
+        ab.v1[r] = 0;
+      }
+    }
+    return ab;
+  };
+  struct BReg { f16x8 t[2]; };
+  struct AReg { f32x4 v[2]; };
+  BReg b[NBG];
+  AReg a[NA][R];
+  // weight entry e = 4*kb + g over the step's block sequence (input blocks, then recurrent blocks)
+  auto loadB = [&](int e, BReg& bb) __attribute__((always_inline)) {
+    bb.t[0] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2) * 1024));
+    bb.t[1] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + 1) * 1024));
+  };
+  auto loadA_in = [&](const ABase& ab, int kb, int r, AReg& d) __attribute__((always_inline)) {
+    if (KQ1 == 0 || kb < KB0) {
+      d.v[0] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048);
+      d.v[1] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048 + 1024);
+    } else {
+      d.v[0] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048);
+      d.v[1] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048 + 1024);
+    }
+  };
+  auto loadA_rec = [&](const float* hp, int kbr, int r, AReg& d) __attribute__((always_inline)) {
+    const float* qh = hp + kbr * 4 * PLANE + r * 128;
+    d.v[0] = *(const f32x4*)(qh);
+    d.v[1] = *(const f32x4*)(qh + PLANE);
+  };
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};          // lo*hi, hi*lo, hi*hi
+
+  // ---- the VALU work of a step, cut into PIECES of at most ~5 instructions ------------------------
+  // An MFMA holds the SIMD's issue port for 8 of its 32 cycles; what a wave issues in the other 24 is
+  // free, what exceeds them delays the next MFMA (the wave issues in order).  hipcc's scheduler does
+  // not spread a dependent chain (one gate element is ~25 dependent instructions) between MFMAs by
+  // itself, so the chains are cut by hand into stages, one stage per MFMA "tick", each tick fenced.
+  constexpr int NE = 16 * R;                                   // gate elements per lane
+  constexpr int GST = 6;                                       // stages of one gate element
+  struct GateSt { float zi, zf, zg, zo, cp, p, hv; };
+  auto gate_stage = [&](GateSt& g, const f32x16 (&Z)[4][R], float* hw, int e, int st) __attribute__((always_inline)) {
+    const int r = e / 16, reg = e % 16;
+    if (st == 0) {
+      g.zi = Z[0][r][reg]; g.zf = Z[1][r][reg]; g.zg = Z[2][r][reg]; g.zo = Z[3][r][reg];
+      if constexpr (CLDS) g.cp = cl[e * NTHREADS + threadIdx.x];
+      else g.cp = c[r][reg];
+    } else if (st == 1) {
+      if constexpr (ACT == 0) {
+        g.zi = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(g.zi, dsc02, kI), 0.0f), 1.0f);
+        g.zf = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(g.zf, dsc02, kF), 0.0f), 1.0f);
+        g.zo = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(g.zo, dsc02, kO), 0.0f), 1.0f);
+      } else {
+        g.zi = sigmoid_exact(__builtin_fmaf(g.zi, dsc, bz[0]));
+        g.zf = sigmoid_exact(__builtin_fmaf(g.zf, dsc, bz[1]));
+        g.zo = sigmoid_exact(__builtin_fmaf(g.zo, dsc, bz[3]));
+      }
+      g.zg = __builtin_amdgcn_exp2f(__builtin_fmaf(g.zg, dsc2, kG));
+    } else if (st == 2) {
+      const float gg = __builtin_fmaf(__builtin_amdgcn_rcpf(g.zg + 1.0f), -2.0f, 1.0f);
+      g.p = g.zi * gg;
+    } else if (st == 3) {
+      const float cn = __builtin_fmaf(g.zf, g.cp, g.p);
+      if constexpr (CLDS) cl[e * NTHREADS + threadIdx.x] = cn;
+      else c[r][reg] = cn;
+      g.zg = __builtin_amdgcn_exp2f(cn * 2.885390081777927f);
+    } else if (st == 4) {
+      // og * tanh(c) * 2^13, the scale riding on tanh's last fma
+      const float th = __builtin_fmaf(__builtin_amdgcn_rcpf(g.zg + 1.0f), -2.0f * kHScale, kHScale);
+      g.hv = g.zo * th;
+    } else {
+      hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = g.hv;
+    }
+  };
+  constexpr int ITEMS = OUT_F32 ? (H / 4) * ROWS : (H / 16) * 2 * ROWS;
+  constexpr int NIT = (ITEMS + NTHREADS - 1) / NTHREADS;
+  static_assert(ITEMS % NTHREADS == 0, "copy-out items must divide evenly");
+  constexpr int CST = OUT_F32 ? 3 : 8;                         // stages of one copy-out item
+  struct CopySt { f32x4 x0, x1, s0, s1, h0, h1; Split2 o; float* dst; };
+  auto copy_stage = [&](CopySt& k, const float* himg, int t, int i, int st) __attribute__((always_inline)) {
+    const int it = threadIdx.x + i * NTHREADS;
+    if constexpr (OUT_F32) {
+      constexpr int KQH = H / 4;
+      const int kq = it / ROWS, rr = it % ROWS;
+      if (st == 0) {
+        k.x0 = *(const f32x4*)(himg + kq * PLANE + rr * 4);
+        k.s0 = *(const f32x4*)(bnl + kq * 4);
+        k.h0 = *(const f32x4*)(bnl + H + kq * 4);
+        const int tile = blk.rowblk * (R * WR) + rr / 32;
+        k.dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
+      } else if (st == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k.x0[q] = k.x0[q] * k.s0[q] + k.h0[q];
+      } else {
+        *(f32x4*)k.dst = k.x0;
+      }
+    } else {
+      constexpr int KBH = H / 16;
+      const int kbh = it / ROWS, rr = it % ROWS;        // kbh = 2*kbo + hf: features 8*kbh .. 8*kbh + 7
+      const int kq = 2 * kbh;
+      if (st == 0) {
+        k.x0 = *(const f32x4*)(himg + kq * PLANE + rr * 4);
+        k.x1 = *(const f32x4*)(himg + (kq + 1) * PLANE + rr * 4);
+        k.s0 = *(const f32x4*)(bnl + kq * 4); k.s1 = *(const f32x4*)(bnl + kq * 4 + 4);
+        k.h0 = *(const f32x4*)(bnl + H + kq * 4); k.h1 = *(const f32x4*)(bnl + H + kq * 4 + 4);
+        const int tile = blk.rowblk * (R * WR) + rr / 32;
+        k.dst = P.out + ((size_t)(tile * T + t) * (2 * H / 4) + (dir * KBH + (kbh >> 1)) * 4 + (kbh & 1)) * 128 + (rr & 31) * 4;
+      } else if (st == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k.x0[q] = k.x0[q] * k.s0[q] + k.h0[q];
+      } else if (st == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k.x1[q] = k.x1[q] * k.s1[q] + k.h1[q];
+      } else if (st < 7) {                              // the split, two elements per stage
+        const int j0 = 2 * (st - 3);
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j) {
+          const float x = j < 4 ? k.x0[j] : k.x1[j - 4];
+          const _Float16 hh = (_Float16)x;
+          k.o.t[0][j] = hh;
+          k.o.t[1][j] = (_Float16)(x - (float)hh);
+        }
+      } else {
+        *(f16x8*)k.dst = k.o.t[0];
+        *(f16x8*)(k.dst + 2 * 128) = k.o.t[1];
+      }
+    }
+  };
+  // the split stage above covers elements 0..7 in stages 3..6
+  static_assert(OUT_F32 || CST == 8, "copy-out stage table");
+
+  // ---- in(): N = b + x W over the input blocks of step sx (bases xb), one MFMA per TICK.  The gate
+  // stages of Z occupy the ticks [0, TG), the barrier follows tick TG - 1, the copy-out stages of the
+  // finished image take the ticks behind it.  WORK = false: the prologue (no Z yet).
+  // hp_next: image the following rec() reads; its first LA blocks are requested here, behind the barrier.
+  constexpr int NTICK = KB_IN * 4 * 3 * R;
+  constexpr int NGP = NE * GST, NCP = NIT * CST;               // pieces
+  constexpr int TG_WANT = NGP < (2 * NTICK) / 3 ? NGP : (2 * NTICK) / 3;
+  constexpr int TG_MAX = (KB_IN - LA) * 4 * 3 * R;             // the rec() operands are requested from block KB_IN - LA on
+  constexpr int TG = TG_WANT < TG_MAX ? TG_WANT : TG_MAX;
+  constexpr int TC = NTICK - TG;
+  static_assert(TG >= 1 && TC >= 1, "no room for the gates / copy-out in the input phase");
+  auto in_phase = [&](auto work_tag, f32x16 (&N)[4][R], const f32x16 (&Z)[4][R], const ABase& xb,
+                      const float* hp_next, float* himg_w, int t_out) __attribute__((always_inline)) {
+    constexpr bool WORK = decltype(work_tag)::value;
+    GateSt gs;
+    CopySt cs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < R; ++r) N[g][r] = splat16(0.0f);
+#pragma unroll
+    for (int kb = 0; kb < KB_IN; ++kb) {
+      {
+        const int ka = kb + LA;                          // activations LA blocks ahead: input, then recurrent
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (ka < KB_IN) loadA_in(xb, ka, r, a[ka % NA][r]);
+          else loadA_rec(hp_next, ka - KB_IN, r, a[ka % NA][r]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int e = 4 * kb + g;
+        loadB((e + LBG) % (4 * KB), b[(e + LBG) % NBG]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr) {
+            const int tk = (e * R + r) * 3 + pr;
+            N[g][r] = mfma_f16(__builtin_bit_cast(f16x8, a[kb % NA][r].v[PA[pr]]), b[e % NBG].t[PB[pr]], N[g][r]);
+            if constexpr (WORK) {
+              if (tk < TG) {
+#pragma unroll
+                for (int pc = (tk * NGP) / TG; pc < ((tk + 1) * NGP) / TG; ++pc)
+                  gate_stage(gs, Z, himg_w + hw_off, pc / GST, pc % GST);
+              } else {
+#pragma unroll
+                for (int pc = ((tk - TG) * NCP) / TC; pc < ((tk - TG + 1) * NCP) / TC; ++pc)
+                  copy_stage(cs, himg_w, t_out, pc / CST, pc % CST);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              if (tk == TG - 1) __syncthreads();         // h_s complete: rec(s+1) operands and the copy-out may read it
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // ---- rec(): Z += h U over the recurrent blocks of the image at hp; the split of the next block's
+  // units runs in the shadow of this block's MFMAs.  The first LA input blocks of the in() phase that
+  // follows (bases xb_next) are requested here.
+  auto rec_phase = [&](f32x16 (&Z)[4][R], const float* hp, const ABase& xb_next) __attribute__((always_inline)) {
+    Split2 sp[2][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sp[0][r] = split2(a[KB_IN % NA][r].v[0], a[KB_IN % NA][r].v[1]);
+#pragma unroll
+    for (int kr = 0; kr < KB_REC; ++kr) {
+      const int kb = KB_IN + kr;
+      {
+        const int ka = kb + LA;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (ka < KB) loadA_rec(hp, ka - KB_IN, r, a[ka % NA][r]);
+          else loadA_in(xb_next, ka - KB, r, a[ka % NA][r]);
+        }
+      }
+      if (kr + 1 < KB_REC) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sp[(kr + 1) & 1][r] = split2(a[(kb + 1) % NA][r].v[0], a[(kb + 1) % NA][r].v[1]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int e = 4 * kb + g;
+        loadB((e + LBG) % (4 * KB), b[(e + LBG) % NBG]);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+            Z[g][r] = mfma_f16(sp[kr & 1][r].t[PA[pr]], b[e % NBG].t[PB[pr]], Z[g][r]);
+      }
+      // one scheduling region per k-block: [A refill][per gate: 2 weight loads, 3R x (MFMA, 2 split ops)]
+      __builtin_amdgcn_sched_group_barrier(0x120, 2 * R, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * R; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Z: b + x_s W (+ h_{s-1} U after rec()); N: the next step's input projection.  At the end of a step
+  // N is moved into Z (128 v_accvgpr_mov at R = 2, ~3 % of a step).  Alternating the roles of two sets
+  // in a body unrolled x2 avoids the moves on paper, but hipcc then cannot keep either set in place
+  // across the loop edge (it inserted more moves than this, plus 64 spilled registers).
+  f32x16 Z[4][R], N[4][R];
+  auto himg = [&](int s) __attribute__((always_inline)) { return hbuf + ((s + 1) & 1) * HBUF; };   // image of h_s
+  auto t_of = [&](int s) __attribute__((always_inline)) { return dir ? (T - 1 - s) : s; };
+
+  // prologue: the rings' first entries, then in(0) straight into Z
+  {
+    const ABase x0 = mk_base(0);
+#pragma unroll
+    for (int e = 0; e < LBG; ++e) loadB(e, b[e]);
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r) loadA_in(x0, i, r, a[i][r]);
+    in_phase(std::false_type{}, Z, Z, x0, himg(-1) + hp_off, nullptr, 0);
+  }
+#pragma unroll 1
+  for (int s = 0; s < T; ++s) {
+    // step s: Z holds b + x_s W on entry; on exit it holds b + x_{s+1} W and h_s is written out
+    const ABase xn = mk_base(s + 1);
+    rec_phase(Z, himg(s - 1) + hp_off, xn);
+    in_phase(std::true_type{}, N, Z, xn, himg(s) + hp_off, himg(s), t_of(s));
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < R; ++r) Z[g][r] = N[g][r];
   }
 }
 

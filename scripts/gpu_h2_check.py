@@ -8,10 +8,11 @@ from nanoreviser_amd import hoststage as hs
 from nanoreviser_amd.engine import Reviser
 from nanoreviser_amd.weights import load_species
 from nanoreviser_amd import workload as W
+MODES = tuple(os.environ.get("H2_MODES", "bf16x3,f16x2").split(","))
 mg = np.load("tests/golden/model_goldens.npz")
 for sp in ("ecoli", "human"):
     m1, m2 = load_species(sp)
-    for mode in ("bf16x3", "f16x2"):
+    for mode in MODES:
         rv = Reviser(m1, m2, precision=mode)
         worst = [0, 0]; flips = 0
         for key in ("ch10_read5252", "ch13_read2251", "ch141_read5436"):
@@ -33,7 +34,7 @@ sig, rd = W.synth_windows(4096, T)
 d_sig, d_rd = torch.from_numpy(sig).cuda(), torch.from_numpy(rd).cuda()
 p1 = torch.empty(4096, 6, device="cuda"); p2 = torch.empty(4096, 5, device="cuda")
 a1 = torch.empty(4096, dtype=torch.int8, device="cuda"); a2 = torch.empty(4096, dtype=torch.int8, device="cuda")
-for mode in ("bf16x3", "f16x2"):
+for mode in MODES:
     rv = Reviser(m1.with_window(T), m2.with_window(T), precision=mode)
     rv.set_stream(torch.cuda.current_stream().cuda_stream)
     args = (d_sig.data_ptr(), d_rd.data_ptr(), 4096, p1.data_ptr(), p2.data_ptr(), a1.data_ptr(), a2.data_ptr())

@@ -25,7 +25,7 @@ from nanoreviser_amd import hoststage as hs
 pytestmark = pytest.mark.gpu
 
 BAR = 1e-4
-MODES = ["bf16x3", "f32"]
+MODES = ["f16x2", "bf16x3", "f32"]
 
 
 def f32_floor(m1, m2, sig, rd, p64_1, p64_2, T=11, numpy_too=True):

@@ -59,7 +59,7 @@ def test_oracle_matches_keras(reads, species_models, sp):
 
 @need_file
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("prec", ["f16x2", "bf16x3", "f32"])
 @pytest.mark.parametrize("sp", ["ecoli", "human"])
 def test_hip_matches_keras(reads, species_models, sp, prec):
     from nanoreviser_amd.engine import Reviser
