@@ -358,12 +358,12 @@ lstm_h2_kernel(const LstmH2Args args) {
 //     rec(s):   Z += h_{s-1} U          recurrent blocks, the operand split in their own shadow
 //     in(s+1):  N  = b + x_{s+1} W      input blocks; between their MFMA groups: the gate elements of
 //                                       Z, then the barrier, then the copy-out items of h_s
-//     Z <-> N                           two accumulator sets, roles alternate: the body is unrolled x2
+//     Z <- N                            two accumulator sets; N is moved into Z at the end of the step
 // so that the serial section of a step is rec(s) alone.  The weight ring is kept per (k-block, gate)
 // entry (8 registers, NBG - 1 entries of lead) instead of per k-block: at R = 2 the two accumulator
-// sets take all 256 AGPRs and everything else must fit the 256 VGPRs.  The in() phase behind the last
-// step computes a product nobody reads (4.6 % of the 192->128 layer's MFMAs) and step 0's rec() runs
-// against a zeroed image (3 %): both keep the code to two bodies that fit the instruction cache.
+// sets take all 256 AGPRs and everything else must fit the 256 VGPRs.  Step 0 has no rec() (h_{-1} = 0:
+// the prologue's requests wrap around to step 1's input blocks instead) and the last step no in()
+// (its gates run plainly): no MFMA is issued whose product is not used.
 // ---------------------------------------------------------------------------------------
 template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int NBG, int NA>
 __global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
@@ -430,7 +430,7 @@ lstm_h2o_kernel(const LstmH2Args args) {
     unsigned v0[R], v1[R];
   };
   auto mk_base = [&](int s) __attribute__((always_inline)) {
-    const int sc = s < T ? s : T - 1;                    // a step past the end aliases the last one (unused product)
+    const int sc = s < T ? s : T - 1;                    // a step past the end aliases the last one (requests nobody consumes)
     const int t = dir ? (T - 1 - sc) : sc;
     ABase ab;
 #pragma unroll
@@ -582,7 +582,9 @@ lstm_h2o_kernel(const LstmH2Args args) {
   constexpr int TC = NTICK - TG;
   static_assert(TG >= 1 && TC >= 1, "no room for the gates / copy-out in the input phase");
   auto in_phase = [&](auto work_tag, f32x16 (&N)[4][R], const f32x16 (&Z)[4][R], const ABase& xb,
-                      const float* hp_next, float* himg_w, int t_out) __attribute__((always_inline)) {
+                      const float* hp_next, float* himg_w, int t_out, const ABase& xb_wrap) __attribute__((always_inline)) {
+    // WORK = false is the prologue, in(0): step 0 has no recurrent blocks (h_{-1} = 0), so what follows
+    // it is in(1), and its tail requests wrap around to the input blocks / weights of step 1 (xb_wrap)
     constexpr bool WORK = decltype(work_tag)::value;
     GateSt gs;
     CopySt cs;
@@ -597,13 +599,14 @@ lstm_h2o_kernel(const LstmH2Args args) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           if (ka < KB_IN) loadA_in(xb, ka, r, a[ka % NA][r]);
-          else loadA_rec(hp_next, ka - KB_IN, r, a[ka % NA][r]);
+          else if (WORK) loadA_rec(hp_next, ka - KB_IN, r, a[ka % NA][r]);
+          else loadA_in(xb_wrap, ka - KB_IN, r, a[ka % NA][r]);
         }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int e = 4 * kb + g;
-        loadB((e + LBG) % (4 * KB), b[(e + LBG) % NBG]);
+        loadB(WORK ? (e + LBG) % (4 * KB) : (e + LBG) % (4 * KB_IN), b[(e + LBG) % NBG]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -676,35 +679,52 @@ lstm_h2o_kernel(const LstmH2Args args) {
     }
   };
 
-  // Z: b + x_s W (+ h_{s-1} U after rec()); N: the next step's input projection.  At the end of a step
-  // N is moved into Z (128 v_accvgpr_mov at R = 2, ~3 % of a step).  Alternating the roles of two sets
-  // in a body unrolled x2 avoids the moves on paper, but hipcc then cannot keep either set in place
-  // across the loop edge (it inserted more moves than this, plus 64 spilled registers).
+  // Z: x_s W (+ h_{s-1} U after rec()); N: the next step's input projection.  At the end of a step N is
+  // moved into Z (128 v_accvgpr_mov at R = 2, ~3 % of a step).  Alternating the roles of two sets in a
+  // body unrolled x2 avoids the moves on paper, but hipcc then cannot keep either set in place across
+  // the loop edge (it inserted more moves than this, plus 64 spilled registers).
   f32x16 Z[4][R], N[4][R];
   auto himg = [&](int s) __attribute__((always_inline)) { return hbuf + ((s + 1) & 1) * HBUF; };   // image of h_s
   auto t_of = [&](int s) __attribute__((always_inline)) { return dir ? (T - 1 - s) : s; };
 
   // prologue: the rings' first entries, then in(0) straight into Z
   {
-    const ABase x0 = mk_base(0);
+    const ABase x0 = mk_base(0), x1 = mk_base(1);
 #pragma unroll
-    for (int e = 0; e < LBG; ++e) loadB(e, b[e]);
+    for (int e = 0; e < LBG; ++e) loadB(e % (4 * KB_IN), b[e]);
 #pragma unroll
     for (int i = 0; i < LA; ++i)
 #pragma unroll
       for (int r = 0; r < R; ++r) loadA_in(x0, i, r, a[i][r]);
-    in_phase(std::false_type{}, Z, Z, x0, himg(-1) + hp_off, nullptr, 0);
+    in_phase(std::false_type{}, Z, Z, x0, nullptr, nullptr, 0, x1);
   }
 #pragma unroll 1
   for (int s = 0; s < T; ++s) {
-    // step s: Z holds b + x_s W on entry; on exit it holds b + x_{s+1} W and h_s is written out
+    // step s: Z holds x_s W on entry; on exit it holds x_{s+1} W and h_s has been written out
     const ABase xn = mk_base(s + 1);
-    rec_phase(Z, himg(s - 1) + hp_off, xn);
-    in_phase(std::true_type{}, N, Z, xn, himg(s) + hp_off, himg(s), t_of(s));
+    if (s > 0) rec_phase(Z, himg(s - 1) + hp_off, xn);
+    if (s + 1 < T) {
+      in_phase(std::true_type{}, N, Z, xn, himg(s) + hp_off, himg(s), t_of(s), xn);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < R; ++r) Z[g][r] = N[g][r];
+        for (int r = 0; r < R; ++r) Z[g][r] = N[g][r];
+    } else {
+      // the last step has no input projection to hide behind: plain gates, barrier, copy-out
+      GateSt gs;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+#pragma unroll
+        for (int st = 0; st < GST; ++st) gate_stage(gs, Z, himg(s) + hw_off, e, st);
+        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the accumulator read-out local
+      }
+      __syncthreads();
+      CopySt cs;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+#pragma unroll
+        for (int st = 0; st < CST; ++st) copy_stage(cs, himg(s), t_of(s), i, st);
+    }
   }
 }
 
