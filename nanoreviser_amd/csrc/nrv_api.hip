@@ -475,7 +475,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     };
     std::vector<float> sc1, sh1, sc2, sh2, sc3, sh3;
     const int sX1 = bn_exp(18, 32, sc1, sh1), sX2 = bn_exp(28, 128, sc2, sh2), sX3 = bn_exp(40, 256, sc3, sh3);
-    const int sS = 6;
+    constexpr int sS = 6;
     auto put_scaled = [&](const std::vector<float>& v, int e) {
       std::vector<float> t(v.size());
       for (size_t i = 0; i < v.size(); ++i) t[i] = std::ldexp(v[i], e);

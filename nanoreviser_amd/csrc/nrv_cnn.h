@@ -125,6 +125,11 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
   constexpr int IMG = 100 * PLANE;
   __shared__ __attribute__((aligned(16))) float img[2 * IMG];
   __shared__ __attribute__((aligned(16))) float part[SPLIT ? 2 * 2 * 16 * 64 : 4];   // [buf][nh][reg][lane]
+  // The 264 conv constants, read as LDS broadcasts.  From global memory every conv thread needs all of
+  // them for every tile: 172 wave-wide loads of ONE address each, and each of them occupies the
+  // vector-memory return path like any other 1 KB load (round 2: that path, not the FMAs, bounded the
+  // convolution; a 12-wave variant with twice the conv threads ran 127 us instead of 91 for that reason).
+  __shared__ __attribute__((aligned(16))) float cwl[264];
 
   const CnnModelParams& P = args.m[blockIdx.y];
   const int T = args.T;
@@ -132,6 +137,9 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
   const int lane = threadIdx.x & 63;
   const int ntile = args.n_tiles, G = gridDim.x;
   const int nloc = (ntile - (int)blockIdx.x + G - 1) / G;     // tiles of this workgroup: b = blockIdx.x + i*G
+
+  for (int i = threadIdx.x; i < 264; i += kCnnThreads) cwl[i] = P.conv[i];
+  __syncthreads();
 
   if (wave >= kCnnMatWaves) {
     // ================================ CONV role ==============================================
@@ -169,8 +177,11 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
         float xn[11];
         load_x(blockIdx.x + (i + 1) * G, xn);        // next tile's samples: a whole iteration of lead
         float* flat = img + (i & 1) * IMG;
-        if (cwv == 0) conv_positions<7>(P.conv, x, p0, r, flat, PLANE);
-        else conv_positions<6>(P.conv, x, p0, r, flat, PLANE);
+        int zoff = 0;                                // opaque zero: keeps LICM from hoisting the 264 reads out of the tile loop
+        asm volatile("" : "+v"(zoff));
+        const float* cw = cwl + zoff;
+        if (cwv == 0) conv_positions<7>(cw, x, p0, r, flat, PLANE);
+        else conv_positions<6>(cw, x, p0, r, flat, PLANE);
 #pragma unroll
         for (int k = 0; k < 11; ++k) x[k] = xn[k];
       }
