@@ -278,6 +278,58 @@ NRV_HOST_COLD static void pack_cnn_split(const float* W, std::vector<float>& out
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
+// head_h2_kernel: the three per-timestep dense layers as f16x2 A operands of the transposed product,
+// 42 fragments x 2 terms [64 lanes][8 f16], in the k order of pack_head_split (dense1: f = 16*kb + 8*h + j;
+// dense2 / main_out: reg = 8*(kb&1) + j, f = 32*(kb>>1) + (reg&3) + 8*(reg>>2) + 4*h), each layer's weights
+// x 2^u, biases x 2^E.  The scales: the input is h x 2^13 (|h| < 1); layer outputs are bounded by
+// sum|W| * (input bound) + |b|, which fixes the exponent s that brings them into the f16 range;
+// E1 = 13 + u1, E2 = s1 + u2, E3 = s2 + u3 are the accumulator exponents.
+struct HeadH2Scales { float c12, c23, c3o; };
+NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>& out, std::vector<float>& bias) {
+  const float *W1 = b.t(50), *B1 = b.t(51), *W2 = b.t(52), *B2 = b.t(53), *W3 = b.t(54), *B3 = b.t(55);
+  const int u1 = pow2_room(max_abs(W1, 128 * 128)), u2 = pow2_room(max_abs(W2, 128 * 32)), u3 = pow2_room(max_abs(W3, 32 * 6));
+  float bound1 = 0.f, bound2 = 0.f;
+  for (int n = 0; n < 128; ++n) {
+    float a = std::fabs(B1[n]);
+    for (int k = 0; k < 128; ++k) a += std::fabs(W1[(size_t)k * 128 + n]);
+    bound1 = std::fmax(bound1, a);
+  }
+  for (int n = 0; n < 32; ++n) {
+    float a = std::fabs(B2[n]);
+    for (int k = 0; k < 128; ++k) a += std::fabs(W2[(size_t)k * 32 + n]) * bound1;
+    bound2 = std::fmax(bound2, a);
+  }
+  const int s1 = pow2_room(bound1), s2 = pow2_room(bound2);
+  const int E1 = 13 + u1, E2 = s1 + u2, E3 = s2 + u3;
+  std::vector<uint16_t> w((size_t)84 * 512, 0);
+  auto emit = [&](int fragbase, float v, int lane, int j) {
+    const size_t o = ((size_t)fragbase * 64 + lane) * 8 + j;
+    split_f16(v, &w[o], &w[o + 512]);
+  };
+  for (int lane = 0; lane < 64; ++lane)
+    for (int j = 0; j < 8; ++j) {
+      const int h = lane >> 5, n = lane & 31;
+      for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < 8; ++kb)
+          emit((mt * 8 + kb) * 2, std::ldexp(W1[(size_t)(16 * kb + 8 * h + j) * 128 + mt * 32 + n], u1), lane, j);
+      for (int kb = 0; kb < 8; ++kb) {
+        const int reg = 8 * (kb & 1) + j, f = 32 * (kb >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        emit(64 + kb * 2, std::ldexp(W2[(size_t)f * 32 + n], u2), lane, j);
+      }
+      for (int kb = 0; kb < 2; ++kb) {
+        const int reg = 8 * kb + j, f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        emit(80 + kb * 2, n < 6 ? std::ldexp(W3[(size_t)f * 6 + n], u3) : 0.f, lane, j);
+      }
+    }
+  out.assign(w.size() / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+  bias.assign(192, 0.f);
+  for (int i = 0; i < 128; ++i) bias[i] = std::ldexp(B1[i], E1);
+  for (int i = 0; i < 32; ++i) bias[128 + i] = std::ldexp(B2[i], E2);
+  for (int i = 0; i < 6; ++i) bias[160 + i] = std::ldexp(B3[i], E3);
+  return HeadH2Scales{std::ldexp(1.f, s1 - E1), std::ldexp(1.f, s2 - E2), std::ldexp(1.f, -E3)};
+}
+
 // lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
 //   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
 //   recurrent step s (0..3): U[unit = 4*(lane>>4) + s][g*16 + (lane&15)]  (lane quarter q holds the
@@ -358,6 +410,8 @@ struct DevModel {
   size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
   float descale[4];
   size_t l1s2, l1h2, dsplit2, dbias2;
+  size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
+  HeadH2Scales hsc;
   int C;
 };
 
@@ -492,7 +546,10 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     const int K0[4] = {0, 32, 128, 256}, K1[4] = {0, 0, 64, 0}, s0[4] = {0, sX1, sX2, sX3}, s1[4] = {0, 0, sS, 0};
     const std::vector<float>* osc[4] = {nullptr, &sc2, &sc3, nullptr};
     const std::vector<float>* osh[4] = {nullptr, &sh2, &sh3, nullptr};
-    const int sout[4] = {0, sX2, sX3, 0};
+    const int sout[4] = {0, sX2, sX3, 13};           // the 256->64 layer has no BatchNorm: its output stays h x 2^13
+    d.hsc = pack_head_h2(b, wp, bs);
+    d.h_w2 = put(wp.data(), wp.size());
+    d.h_b2 = put(bs.data(), bs.size());
     for (int l = 1; l < 4; ++l) {
       const int E = plan_exponent(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l]);
       pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs);
@@ -782,8 +839,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     }
     if (h->h2) {
       const ActView i0[2] = {win_view(h->X3[0], 64), win_view(h->X3[1], 64)};
-      float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2, f32 tiles for the head
-      launch_lstm_h2<64, 0, 64, 1, 2, true, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
+      float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2; split planes for head_h2_kernel
+      launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
@@ -803,6 +860,19 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       a.m[m] = HeadModelParams{d.all + d.d1p, d.all + d.d1b, d.all + d.d2p, d.all + d.d2b,
                                d.all + d.mop, d.all + d.mob, d.all + d.fw, d.all + d.fb,
                                d.all + d.ow, d.all + d.ob, h->X2[m], h->MO[m], dp[m], da[m], d.C};
+    }
+    if (h->h2) {
+      HeadH2Args ha;
+      ha.T = T; ha.n_rows = n; ha.n_tiles = tiles;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        ha.m[m] = HeadH2ModelParams{d.all + d.h_w2, d.all + d.h_b2, h->X2[m], d.all + d.fw, d.all + d.fb, d.all + d.ow,
+                                    d.all + d.ob, dp[m], da[m], d.hsc.c12, d.hsc.c23, d.hsc.c3o, d.C};
+      }
+      hipLaunchKernelGGL(head_h2_kernel, dim3(tiles < 128 ? tiles : 128, 2), dim3(256), 0, h->stream, ha);
+      if ((rc = mark(6))) return rc;
+      HIPCHK(h, hipGetLastError());
+      return NRV_OK;
     }
     if (h->split & 16) {
       HeadSplitArgs sa;
