@@ -869,7 +869,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         ha.m[m] = HeadH2ModelParams{d.all + d.h_w2, d.all + d.h_b2, h->X2[m], d.all + d.fw, d.all + d.fb, d.all + d.ow,
                                     d.all + d.ob, dp[m], da[m], d.hsc.c12, d.hsc.c23, d.hsc.c3o, d.C};
       }
-      hipLaunchKernelGGL(head_h2_kernel, dim3(tiles < 128 ? tiles : 128, 2), dim3(256), 0, h->stream, ha);
+      hipLaunchKernelGGL(head_h2_kernel, dim3(tiles < 128 ? tiles : 128, 2), dim3(kHeadH2Threads), 0, h->stream, ha);
       if ((rc = mark(6))) return rc;
       HIPCHK(h, hipGetLastError());
       return NRV_OK;

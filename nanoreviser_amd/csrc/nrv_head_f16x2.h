@@ -17,10 +17,10 @@ namespace nrv {
 //     lane = data row; eight accumulator registers of one layer are a B operand of the next), the
 //     power-of-two rescaling between layers (accumulator scale -> f16 range of the next operand,
 //     from static bounds: |h| < 1, hence |z1| <= sum|W1| + |b1|, ...) rides on the ReLU;
-//   * a workgroup owns whole row tiles: its four waves take the T timestep units of a tile, leave the
+//   * a workgroup owns whole row tiles: its eight waves take the T timestep units of a tile, leave the
 //     6 outputs per (row, timestep) in LDS, and after ONE barrier the same workgroup runs the
 //     per-window tail from there - main_out never goes to HBM and the second launch is gone.
-// grid = (min(tiles, 128), 2 models), block = 256; weights of the three layers (84 KB as f16 pairs)
+// grid = (min(tiles, 128), 2 models), block = 512; weights of the three layers (84 KB as f16 pairs)
 // staged once per workgroup.
 // ---------------------------------------------------------------------------------------
 struct HeadH2ModelParams {
@@ -43,7 +43,10 @@ struct HeadH2Args {
   int n_tiles;
 };
 
-__global__ void __launch_bounds__(256) head_h2_kernel(const HeadH2Args args) {
+constexpr int kHeadH2Threads = 512;         // eight waves: two per SIMD, the T units of a tile in two rounds
+
+__global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Args args) {
+  constexpr int NT = kHeadH2Threads, NW = NT / 64;
   constexpr int NFRAG = 84;
   constexpr int TMAX = kHeadMaxT;
   __shared__ __attribute__((aligned(16))) unsigned short wl[NFRAG * 512];
@@ -59,17 +62,17 @@ __global__ void __launch_bounds__(256) head_h2_kernel(const HeadH2Args args) {
   {
     // 84 KB of weights, 8 x 16 B in flight per thread
     const __amdgpu_buffer_rsrc_t srs = make_rsrc(P.wsplit, NFRAG * 1024);
-    for (int base = 0; base < NFRAG * 64; base += 8 * 256) {
+    for (int base = 0; base < NFRAG * 64; base += 8 * NT) {
       f32x4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = buf_load16(srs, (unsigned)(base + j * 256 + tid) * 16, 0);   // out of range -> 0
+      for (int j = 0; j < 8; ++j) v[j] = buf_load16(srs, (unsigned)(base + j * NT + tid) * 16, 0);   // out of range -> 0
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (base + j * 256 + tid < NFRAG * 64) ((f32x4*)wl)[base + j * 256 + tid] = v[j];
+        if (base + j * NT + tid < NFRAG * 64) ((f32x4*)wl)[base + j * NT + tid] = v[j];
     }
   }
   if (tid < 192) bl[tid] = P.bias[tid];
-  for (int i = tid; i < 16 * T * 8; i += 256) {
+  for (int i = tid; i < 16 * T * 8; i += NT) {
     const int f = i / (T * 8), t = (i / 8) % T, k = i & 7;
     fw8[i] = k < 6 ? P.featw[(t * 6 + k) * 16 + f] : 0.f;
   }
@@ -108,10 +111,10 @@ __global__ void __launch_bounds__(256) head_h2_kernel(const HeadH2Args args) {
   };
 
   for (int tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
-    // ---- per-timestep MLP: wave w takes timesteps w, w + 4, ...
+    // ---- per-timestep MLP: wave w takes timesteps w, w + 8, ...
     f32x4 x[8][2];
     if (wave < T) load_x(tile * T + wave, x);
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += NW) {
       f32x16 acc[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = bias_tile(mt * 32);
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) head_h2_kernel(const HeadH2Args args) {
         __builtin_amdgcn_sched_barrier(0);
       }
       // the next unit's inputs travel while the two small layers run
-      if (t + 4 < T) load_x(tile * T + t + 4, x);
+      if (t + NW < T) load_x(tile * T + t + NW, x);
       // dense2: 128 -> 32; k-block kb takes registers 8*(kb&1).. of tile kb>>1 (two accumulators: the 24
       // products would otherwise form one dependent chain)
       f32x16 a2[2];
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(256) head_h2_kernel(const HeadH2Args args) {
     __syncthreads();
 
     // ---- per-window tail of this tile: Flatten(6T) -> Dense(16,relu) -> Dense(C,softmax) -> argmax
-    for (int it = tid; it < 32 * 16; it += 256) {
+    for (int it = tid; it < 32 * 16; it += NT) {
       const int r = it >> 4, f = it & 15;
       float v = P.featb[f];
       for (int t = 0; t < T; ++t) {
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(256) head_h2_kernel(const HeadH2Args args) {
     }
     __syncthreads();
     const int C = P.n_class;
-    {
+    if (tid < 256) {
       const int r = tid >> 3, cc = tid & 7;
       if (cc < C) {
         float v = P.outb[cc];
