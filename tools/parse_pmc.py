@@ -21,6 +21,8 @@ def short(name):
             ", ".join(m.groups()), name)
     if "lstm1_kernel" in name:
         return "lstm1"
+    if "head_h2_kernel" in name:
+        return "head_h2_kernel"
     if "head_mlp_split_kernel" in name:
         return "head_mlp_kernel"
     for k in ("cnn_kernel", "head_mlp_kernel", "head_final_kernel", "head_kernel"):
