@@ -106,16 +106,21 @@ int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d
 int nrv_set_batch(nrv_handle* h, int batch_windows);
 int nrv_get_batch(nrv_handle* h);
 
-/* Matrix arithmetic of the three large Bi-LSTM layers (32->64, 192->128, 256->64), the
- * per-timestep dense layers (128->128->32->6) and the signal branch's 400->64 layer: 98 % of the FLOPs.  Both modes accumulate in f32 and
- * meet the same parity bars (every test of tests/test_gpu_parity.py runs once per mode):
- *   NRV_PREC_BF16X3 (default)  every f32 operand is split exactly into three bf16 terms and each
- *                    product formed from the six term pairs that matter, on the bf16 matrix pipe;
- *                    errors vs fp64 are those of the f32 pipe, at ~0.7x its time;
+/* Matrix arithmetic of the three large Bi-LSTM layers (32->64, 192->128, 256->64), the per-timestep
+ * dense layers (128->128->32->6) and the signal branch's 400->64 layer: 98 % of the FLOPs.  All modes
+ * accumulate in f32 and meet the same parity bars (every test of tests/test_gpu_parity.py runs once per
+ * mode; DESIGN.md 5 has the figures over all 81 770 fixture windows: 0 argmax differences in any mode):
+ *   NRV_PREC_F16X2 (default)  every operand is scaled by a power of two fixed at nrv_create from static
+ *                    bounds, split into two f16 terms, and each product formed from three term pairs
+ *                    on the f16 matrix pipe; activations travel between the kernels already split.
+ *                    ~2.2x the f32 mode's throughput.  (The signal branch's 400->64 layer stays on
+ *                    the bf16x3 form: its input has no static bound.)
+ *   NRV_PREC_BF16X3  every f32 operand is split exactly into three bf16 terms and each product formed
+ *                    from the six term pairs that matter, on the bf16 matrix pipe; ~1.5x f32 mode;
  *   NRV_PREC_F32     plain f32 matrix instructions.
- * The convolutions, the first Bi-LSTM (6->16) and the per-window tail are f32 in either mode.
- * Takes effect from the next call.  The environment variable NRV_PRECISION=f32|bf16x3 sets the mode
- * a new handle starts in. */
+ * The convolutions, the first Bi-LSTM (6->16) and the per-window tail are f32 in every mode.
+ * Takes effect from the next call.  The environment variable NRV_PRECISION=f32|bf16x3|f16x2 sets the
+ * mode a new handle starts in. */
 #define NRV_PREC_F32 0
 #define NRV_PREC_BF16X3 1
 #define NRV_PREC_F16X2 2
