@@ -330,6 +330,24 @@ NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>
   return HeadH2Scales{std::ldexp(1.f, s1 - E1), std::ldexp(1.f, s2 - E2), std::ldexp(1.f, -E3)};
 }
 
+// cnn_h2_kernel: dense 400->64 x 2^wexp as f16x2 B fragments of v_mfma_f32_16x16x32_f16:
+// [ks 13][ct 4][term 2][64 lanes][8 f16]; lane l, element j hold W[k][n] with k = 32*ks + 8*(l>>4) + j
+// (flatten index p*8+o; rows >= 400 are zero), n = 16*ct + (l&15).
+NRV_HOST_COLD static void pack_cnn_h2(const float* W, int wexp, std::vector<float>& out) {
+  std::vector<uint16_t> w((size_t)13 * 4 * 2 * 512, 0);
+  for (int ks = 0; ks < 13; ++ks)
+    for (int ct = 0; ct < 4; ++ct)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * ks + 8 * (lane >> 4) + j;
+          const float v = k < 400 ? std::ldexp(W[(size_t)k * 64 + 16 * ct + (lane & 15)], wexp) : 0.f;
+          const size_t o = ((size_t)((ks * 4 + ct) * 2) * 64 + lane) * 8 + j;
+          split_f16(v, &w[o], &w[o + 512]);
+        }
+  out.assign(w.size() / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+}
+
 // lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
 //   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
 //   recurrent step s (0..3): U[unit = 4*(lane>>4) + s][g*16 + (lane&15)]  (lane quarter q holds the
@@ -410,6 +428,7 @@ struct DevModel {
   size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
   float descale[4];
   size_t l1s2, l1h2, dsplit2, dbias2;
+  size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
   size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
   HeadH2Scales hsc;
   int C;
@@ -542,6 +561,18 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     {
       std::vector<float> db(b.t(33), b.t(33) + 64);
       d.dbias2 = put_scaled(db, sS);
+    }
+    {
+      // cnn_h2_kernel: the conv features live in LDS as x 2^6 f16 pairs, the dense weights as x 2^10
+      static_assert(sS == 6, "kImgScale / kDenseDescale in nrv_cnn_f16x2.h assume S x 2^6");
+      float cv[264];
+      memcpy(cv, host.data() + d.conv, 264 * 4);
+      for (int o = 0; o < 8; ++o) { cv[248 + o] = std::ldexp(cv[248 + o], 6); cv[256 + o] = std::ldexp(cv[256 + o], 6); }
+      d.conv_h2 = put(cv, 264);
+      pack_cnn_h2(b.t(32), 10, wp);
+      d.dsplit_h2 = put(wp.data(), wp.size());
+      std::vector<float> db(b.t(33), b.t(33) + 64);
+      d.dbias_h2 = put_scaled(db, 16);
     }
     const int K0[4] = {0, 32, 128, 256}, K1[4] = {0, 0, 64, 0}, s0[4] = {0, sX1, sX2, sX3}, s1[4] = {0, 0, sS, 0};
     const std::vector<float>* osc[4] = {nullptr, &sc2, &sc3, nullptr};
@@ -763,7 +794,16 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     a.n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
     // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
     int blocks = a.n_tiles < 128 ? a.n_tiles : 128;
-    if (h->h2) hipLaunchKernelGGL((cnn_kernel<true, true>), dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+    static const bool old_cnn = getenv("NRV_CNNV") && atoi(getenv("NRV_CNNV")) == 1;   // tuning: cnn_kernel<true,true>
+    if (h->h2 && !old_cnn) {
+      CnnH2Args a2;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        a2.m[m] = CnnH2ModelParams{d.all + d.conv_h2, d.all + d.dsplit_h2, d.all + d.dbias_h2, h->S[m]};
+      }
+      a2.signal = a.signal; a2.T = a.T; a2.n_rows = a.n_rows; a2.n_tiles = a.n_tiles;
+      hipLaunchKernelGGL(cnn_h2_kernel, dim3(blocks, 2), dim3(kCnnH2Threads), 0, h->stream, a2);
+    } else if (h->h2) hipLaunchKernelGGL((cnn_kernel<true, true>), dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     else if (h->split & 32) hipLaunchKernelGGL(cnn_kernel<true>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     else hipLaunchKernelGGL(cnn_kernel<false>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
     if ((rc = mark(1))) return rc;

@@ -22,7 +22,7 @@ namespace nrv {
 //     exactly the two stores the f32 image needed.  The four matrix waves then run the dense layer
 //     with NO VALU work in the loop: wave ct owns 16 output columns as v_mfma_f32_16x16x32_f16 tiles
 //     (two row halves x 13 k-steps x 3 products = 78 MFMAs of 16 cycles per tile), A fragments straight
-//     from LDS, B fragments streamed from L2 (26 KB per wave and tile), no partial sums to exchange.
+//     from LDS, B fragments resident in registers (104 VGPRs), no partial sums to exchange.
 // Roles are separate code paths (waves 0-3 matrix, 4-11 conv), so each has the whole 168-register
 // budget of a 12-wave workgroup to itself; the conv path reads its 264 constants as LDS broadcasts.  (One unified path for all waves was
 // built first: with global stores in the loop hipcc turned the constant loads into per-lane vector
@@ -98,21 +98,22 @@ __device__ __forceinline__ void conv_positions_h2(const lds_f32* cw, const float
     float wrow[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) wrow[o] = wnext[o];
+    if (kc + 1 < 24) {
+      // the next row is requested HERE, in front of this row's FMAs (one row of lead).  Its address hangs
+      // on an opaque zero that the asm produces from the previous row's last result, which pins the read
+      // between the two rows (fences alone did not stop the reads of all 24 rows from being clustered at
+      // the top and spilled)
+      int z;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(acc[NP - 1][7]));
+#pragma unroll
+      for (int o = 0; o < 8; ++o) wnext[o] = w2[(kc + 1) * 8 + o + z];
+    }
     const int k = kc >> 3, ci = kc & 7;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const float av = b1v[q + k][ci];
 #pragma unroll
       for (int o = 0; o < 8; ++o) acc[q][o] = __builtin_fmaf(av, wrow[o], acc[q][o]);
-    }
-    if (kc + 1 < 24) {
-      // the next row is requested HERE, one row of FMAs ahead of its use: its address hangs on an opaque
-      // zero that the asm produces after this row's last FMA (fences alone did not stop the reads of all
-      // 24 rows from being clustered at the top and spilled)
-      int z;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(acc[NP - 1][7]));
-#pragma unroll
-      for (int o = 0; o < 8; ++o) wnext[o] = w2[(kc + 1) * 8 + o + z];
     }
   }
   float s2[8], h2[8];
@@ -189,47 +190,52 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
       }
     };
     load_x(blockIdx.x, x);
-    for (int i = 0; i <= nloc; ++i) {
-      if (i < nloc) {
+    // Two things hipcc's register allocation is sensitive to here (each alone turns 120-133 VGPRs into
+    // > 168 + spills): the loop must not be of the form `for (i = 0; i <= nloc; ++i) { if (i < nloc) {...}
+    // barrier }`, and the two chunk widths must not meet inside one loop body (`cwv == 4 ? <4> : <3>` in the
+    // loop: both variants' registers are summed) - hence one whole tile loop per width.
+    auto tile_loop = [&](auto np_tag) __attribute__((always_inline)) {
+      constexpr int NP = decltype(np_tag)::value;
+      for (int i = 0; i < nloc; ++i) {
         float xn[8];
         load_x(blockIdx.x + (i + 1) * G, xn);      // next tile's samples: a whole iteration of lead
         lds_f16* im = img + (i & 1) * IMG;
         int zoff = 0;                              // opaque zero: keeps LICM from hoisting the 264 reads out of the tile loop
         asm volatile("" : "+v"(zoff));
         const lds_f32* cw = cwl + zoff;
-        if (cwv == 4) conv_positions_h2<4>(cw, x, p0, r, im);
-        else conv_positions_h2<3>(cw, x, p0, r, im);
+        conv_positions_h2<NP>(cw, x, p0, r, im);
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = xn[k];
+        __syncthreads();
       }
-      __syncthreads();
-    }
+    };
+    if (cwv == 4) tile_loop(std::integral_constant<int, 4>{});
+    else tile_loop(std::integral_constant<int, 3>{});
+    __syncthreads();                               // the matrix role's last tile
   } else {
     // ================================ MATRIX role ============================================
-    // wave ct: output columns 16 ct .. +15, all 13 k-steps of 32, both row halves.  The B fragments are
-    // streamed from L2 for every tile (26 KB per wave and tile, two k-steps of lead) instead of living in
-    // registers: hipcc's allocation for a kernel with both roles inlined came out near the SUM of the two
-    // (conv alone 90 VGPRs, this role with resident weights 154, together 168 + 292 spilled).
+    // wave ct: output columns 16 ct .. +15, all 13 k-steps of 32, both row halves; its B fragments (26 KB)
+    // stay in registers for the whole launch
     const int ct = wave;
     const int n16 = lane & 15, kg = lane >> 4;
     constexpr int NKS = 13;
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.dsplit, NKS * 4 * 2 * 1024);
-    const unsigned wv = (unsigned)ct * 2048 + lane * 16;            // + ks * 8192 + term * 1024
+    f16x8 bw[NKS][2];
+#pragma unroll
+    for (int k = 0; k < NKS; ++k)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        bw[k][tm] = *(const f16x8*)((const char*)P.dsplit + ((size_t)((k * 4 + ct) * 2 + tm) * 64 + lane) * 16);
     const float bias = P.dbias[ct * 16 + n16];
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};           // lo*hi, hi*lo, hi*hi
-    for (int i = 0; i <= nloc; ++i) {
-      if (i > 0) {
+    __syncthreads();                               // tile 0 is being convolved
+    for (int i = 1; i <= nloc; ++i) {
+      {
         const lds_f16* im = img + ((i - 1) & 1) * IMG;
         // A fragment of k-step ks, row half rh: lane (row n16, k-group kg) reads k-block 2 ks + (kg >> 1),
         // half kg & 1, event 16 rh + n16
         const lds_f16* ap = im + ((kg >> 1) * 4 + (kg & 1)) * CH + n16 * 8;
         f32x4 acc[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
-        f16x8 bw[3][2];                                                // weights: ring of three k-steps
         f16x8 at[2][2][2];                                             // A: ring of two k-steps [slot][row half][term]
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) bw[k][tm] = __builtin_bit_cast(f16x8, buf_load16(wrs, wv, k * 8192 + tm * 1024));
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
           at[0][rh][0] = *(const lds_f16x8*)(ap + rh * 16 * 8);
@@ -237,11 +243,6 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
         }
 #pragma unroll
         for (int k = 0; k < NKS; ++k) {
-          if (k + 2 < NKS) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-              bw[(k + 2) % 3][tm] = __builtin_bit_cast(f16x8, buf_load16(wrs, wv, (k + 2) * 8192 + tm * 1024));
-          }
           if (k + 1 < NKS) {
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
           for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr)
-              acc[rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[k & 1][rh][PA[pr]], bw[k % 3][PB[pr]], acc[rh], 0, 0, 0);
+              acc[rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[k & 1][rh][PA[pr]], bw[k][PB[pr]], acc[rh], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: S x 2^6 as f16 split planes
