@@ -24,9 +24,15 @@ namespace nrv {
 //     (two row halves x 13 k-steps x 3 products = 78 MFMAs of 16 cycles per tile), A fragments straight
 //     from LDS, B fragments resident in registers (104 VGPRs), no partial sums to exchange.
 // Roles are separate code paths (waves 0-3 matrix, 4-11 conv), so each has the whole 168-register
-// budget of a 12-wave workgroup to itself; the conv path reads its 264 constants as LDS broadcasts.  (One unified path for all waves was
-// built first: with global stores in the loop hipcc turned the constant loads into per-lane vector
-// loads, and the resident dense weights had to share the registers with the convolution: 800 spills.)
+// budget of a 12-wave workgroup to itself; the conv path reads its 264 constants as LDS broadcasts
+// (hand-issued scalar loads, s_load_dwordx8 through inline asm with SGPR operands for the FMAs, run
+// at the same speed; from global memory hipcc makes them per-lane vector loads, because the kernel
+// also stores to global memory).
+// Measured (same box, parts compiled out): whole kernel 80 us; the 8->8 convolution's FMAs 43 us -
+// tools/microbench/valu_waves.hip puts the practical v_fma_f32 rate at 1.4-1.7 ns per wave-instruction
+// and SIMD with 2-4 waves per SIMD (4.4 ns with one), i.e. a floor of ~22 us for them; the dense layer's
+// MFMAs 6 us, its split-plane epilogue stores 2.5 us, everything else (conv1, loads, barriers) 20 us.
+// cnn_kernel<true,true> (4 conv waves, bf16x3 dense): 90 us.
 // Persistent: one workgroup per CU and model, tile i is convolved while tile i-1 is multiplied; one
 // barrier per tile.  Output: f16 split planes of S x 2^6 (the layout lstm_h2o_kernel reads).
 // ---------------------------------------------------------------------------------------

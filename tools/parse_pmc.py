@@ -25,6 +25,8 @@ def short(name):
         return "head_h2_kernel"
     if "head_mlp_split_kernel" in name:
         return "head_mlp_kernel"
+    if "cnn_h2_kernel" in name:
+        return "cnn_h2_kernel"
     for k in ("cnn_kernel", "head_mlp_kernel", "head_final_kernel", "head_kernel"):
         if k in name:
             return k
