@@ -6,18 +6,20 @@
 // with Keras-2.2.4 inference semantics.  Results are IEEE-f32 grade.
 //
 // How it is mapped (MI355X-first, not a translation of TF ops):
-//   * Contractions run on the matrix pipe with f32-exact products: by default as an exact
-//     three-term bf16 split on v_mfma_f32_32x32x16_bf16 (six products per f32 product, f32
-//     accumulation; nrv_lstm_bf16x3.h, head_mlp_split_kernel), or on v_mfma_f32_32x32x2_f32 /
-//     16x16x4 (NRV_PREC_F32, and always for the small layers).
+//   * Contractions run on the matrix pipe with f32-grade products: by default operands scaled by a
+//     static power of two and split into two f16 terms (three products per f32 product, f32
+//     accumulation; nrv_lstm_f16x2.h, nrv_cnn_f16x2.h, nrv_head_f16x2.h); or as an exact three-term
+//     bf16 split on v_mfma_f32_32x32x16_bf16 (six products; nrv_lstm_bf16x3.h, head_mlp_split_kernel);
+//     or on v_mfma_f32_32x32x2_f32 / 16x16x4 (NRV_PREC_F32, and always for the small layers).
 //   * Activations between kernels live in an MFMA-native tiled layout
 //         act[tile32][t][kq][32 rows][4]      (kq = feature/4)
 //     so that one wave-wide 16-byte load IS an A fragment and is a single contiguous 1 KiB request.
 //     Weights are pre-packed on the host into the matching B-fragment order (f32 and split-bf16
 //     forms), so B operands stream L2 -> VGPR with no LDS staging.
-//   * Seven launches per group of windows: cnn_kernel (signal branch), lstm1_kernel, three Bi-LSTM
-//     layer launches (lstm_pair_kernel / lstm_split_kernel, or lstm_layer_kernel in f32 mode),
-//     head_mlp(_split)_kernel, head_final_kernel; plus segment_kernel when reads arrive as raw
+//   * Six launches per group of windows in the default mode: cnn_h2_kernel (signal branch),
+//     lstm1_kernel, three lstm_h2o_kernel Bi-LSTM layers, head_h2_kernel (seven in the other modes:
+//     cnn_kernel, lstm1_kernel, lstm_pair_kernel / lstm_split_kernel or lstm_layer_kernel,
+//     head_mlp(_split)_kernel, head_final_kernel); plus segment_kernel when reads arrive as raw
 //     samples.  Rows (windows) are independent: no inter-workgroup communication anywhere.
 //   * One Bi-LSTM layer = one launch; a wave owns 32 hidden units x 4 gates x R row tiles, so
 //     i,f,g,o of one (window, unit) sit in the same lane/register and the cell update is
