@@ -183,35 +183,38 @@ static inline void split_f16(float v, uint16_t* hi, uint16_t* lo) {
 // [dir][hg][kb][gate][term 2][64 lanes][8 f16]; lane l holds k = 16*kb + 8*(l>>5) + j, column (gate,
 // unit hg*32 + (l&31)); input rows k < K0 are scaled by 2^(E - s0), k >= K0 by 2^(E - s1), recurrent
 // rows by 2^(E - 13).  bias [dir][hg][gate][32] x 2^E.
+// gpt = gates per 32-column tile (lstm_h2o_kernel's GPT): a wave's group holds upw = 32 / gpt hidden units and
+// 4 / gpt tiles per k-block; column n of tile tl is gate tl gpt + n / upw of unit n % upw.
 NRV_HOST_COLD static void pack_lstm_h2(const Blob& b, int base, int K0, int s0, int K1, int s1, int H, int E,
-                                       std::vector<float>& out, std::vector<float>& bias) {
+                                       std::vector<float>& out, std::vector<float>& bias, int gpt = 1) {
   const int Kin = K0 + K1;
-  const int NG = (H + 31) / 32, KB_IN = Kin / 16, KB = KB_IN + H / 16;
-  std::vector<uint16_t> w((size_t)2 * NG * KB * 4 * 2 * 64 * 8, 0);
-  bias.assign((size_t)2 * NG * 4 * 32, 0.f);
+  const int upw = 32 / gpt, ngt = 4 / gpt;
+  const int NG = (H + upw - 1) / upw, KB_IN = Kin / 16, KB = KB_IN + H / 16;
+  std::vector<uint16_t> w((size_t)2 * NG * KB * ngt * 2 * 64 * 8, 0);
+  bias.assign((size_t)2 * NG * 4 * upw, 0.f);
   for (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
     const float* B = b.t(base + dir * 3 + 2);
     for (int hg = 0; hg < NG; ++hg) {
       for (int kb = 0; kb < KB; ++kb)
-        for (int g = 0; g < 4; ++g)
+        for (int tl = 0; tl < ngt; ++tl)
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
-              const int unit = hg * 32 + (lane & 31);
+              const int n = lane & 31, g = tl * gpt + n / upw, unit = hg * upw + n % upw;
               float v = 0.f;
               if (unit < H) {
                 const int k = 16 * (kb < KB_IN ? kb : kb - KB_IN) + 8 * (lane >> 5) + j;
                 if (kb < KB_IN) v = std::ldexp(W[(size_t)k * 4 * H + g * H + unit], E - (k < K0 ? s0 : s1));
                 else v = std::ldexp(U[(size_t)k * 4 * H + g * H + unit], E - 13);
               }
-              const size_t o = (((((size_t)(dir * NG + hg) * KB + kb) * 4 + g) * 2) * 64 + lane) * 8 + j;
+              const size_t o = (((((size_t)(dir * NG + hg) * KB + kb) * ngt + tl) * 2) * 64 + lane) * 8 + j;
               split_f16(v, &w[o], &w[o + 64 * 8]);
             }
       for (int g = 0; g < 4; ++g)
-        for (int c = 0; c < 32; ++c) {
-          const int unit = hg * 32 + c;
-          bias[((size_t)(dir * NG + hg) * 4 + g) * 32 + c] = unit < H ? std::ldexp(B[g * H + unit], E) : 0.f;
+        for (int c = 0; c < upw; ++c) {
+          const int unit = hg * upw + c;
+          bias[((size_t)(dir * NG + hg) * 4 + g) * upw + c] = unit < H ? std::ldexp(B[g * H + unit], E) : 0.f;
         }
     }
   }
@@ -426,6 +429,7 @@ struct DevModel {
   // f16x2 mode (nrv_lstm_f16x2.h): lstm2..4 weights as two f16 terms, scaled biases, output scale /
   // shift with the buffer exponents folded in, the producers' scaled epilogue constants
   size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
+  size_t l_w2g[4], l_b2g[4];        // the same packed two gates per tile (lstm_h2o_kernel GPT = 2)
   float descale[4];
   size_t l1s2, l1h2, dsplit2, dbias2;
   size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
@@ -586,6 +590,9 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs);
       d.l_w2[l] = put(wp.data(), wp.size());
       d.l_b2[l] = put(bs.data(), bs.size());
+      pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, 2);
+      d.l_w2g[l] = put(wp.data(), wp.size());
+      d.l_b2g[l] = put(bs.data(), bs.size());
       d.descale[l] = std::ldexp(1.f, -E);
       // the LDS image holds h * 2^13: scale' = scale * 2^(s_out - 13), shift' = shift * 2^s_out
       std::vector<float> one(2 * lH[l], 1.f), zero(2 * lH[l], 0.f);
@@ -728,28 +735,31 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA, int NBG, int NA>
+template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA, int NBG, int NA, int GPT = 1>
 static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
                            float* const out[2], int T, int n, int tiles) {
-  constexpr int NG = (H + 31) / 32;
+  constexpr int NG = (H * GPT + 31) / 32;
   LstmH2Args sa;
   sa.T = T; sa.n_rows = n;
   for (int m = 0; m < 2; ++m) {
     const DevModel& d = h->dm[m];
-    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2[layer], d.all + d.l_b2[layer], d.all + d.l_s2[layer],
+    sa.m[m] = LstmH2ModelParams{d.all + (GPT == 2 ? d.l_w2g[layer] : d.l_w2[layer]),
+                                d.all + (GPT == 2 ? d.l_b2g[layer] : d.l_b2[layer]), d.all + d.l_s2[layer],
                                 d.all + d.l_h2[layer], in0[m], in1[m], out[m], d.descale[layer]};
   }
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
   // NRV_H2V=1: the plain kernel (gates after the matrix phase) instead of the overlapped one
-  static const bool plain = getenv("NRV_H2V") && atoi(getenv("NRV_H2V")) == 1;
-  if (plain) {
-    if (h->act == 0) hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
-    else hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
-    return;
+  if constexpr (GPT == 1) {
+    static const bool plain = getenv("NRV_H2V") && atoi(getenv("NRV_H2V")) == 1;
+    if (plain) {
+      if (h->act == 0) hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+      else hipLaunchKernelGGL((lstm_h2_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, LB, LA>), grid, blk, 0, h->stream, sa);
+      return;
+    }
   }
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA>), grid, blk, 0, h->stream, sa);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA, GPT>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT>), grid, blk, 0, h->stream, sa);
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -880,7 +890,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     if (h->h2) {
       const ActView i0[2] = {win_view(h->X3[0], 64), win_view(h->X3[1], 64)};
       float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2; split planes for head_h2_kernel
-      launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
+      // NRV_HT=0: one gate per accumulator tile (two pairs of waves, R = 1) instead of two (four waves, R = 2)
+      static const bool ht = !(getenv("NRV_HT") && atoi(getenv("NRV_HT")) == 0);
+      if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2>(h, 3, i0, none, o, T, n, tiles);
+      else launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);

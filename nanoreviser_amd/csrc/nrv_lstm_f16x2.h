@@ -2,6 +2,9 @@
 #pragma once
 #include "nrv_lstm_f32.h"
 
+#ifndef NRV_EXP
+#define NRV_EXP 0
+#endif
 namespace nrv {
 
 // ---------------------------------------------------------------------------------------
@@ -364,27 +367,42 @@ lstm_h2_kernel(const LstmH2Args args) {
 // sets take all 256 AGPRs and everything else must fit the 256 VGPRs.  Step 0 has no rec() (h_{-1} = 0:
 // the prologue's requests wrap around to step 1's input blocks instead) and the last step no in()
 // (its gates run plainly): no MFMA is issued whose product is not used.
+//
+// GPT: gates per 32-column accumulator tile.  1: a wave owns 32 hidden units, one tile per gate.  2: a
+// wave owns 16 units, tile 0 = [i | f], tile 1 = [g | o] (16 columns each): H = 64 then spreads over four
+// waves instead of two pairs of waves that fetch the same weights, each weight fragment feeds R = 2 row
+// tiles, and the CU's vector-memory path carries the layer's weights once per step instead of twice
+// (that path, 64 B/clk, was what paced the 256->64 layer: 768 KB per step against 7.7 k MFMA cycles).
+// The halves of a tile are brought together for the gate math by one v_permlane16_swap per register
+// pair: lanes 0-15 end up with i, f, g, o of rows 0-3 / 8-11 of their unit, lanes 16-31 with rows 16-19 /
+// 24-27 (+4 in the upper half of the wave).
 // ---------------------------------------------------------------------------------------
-template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int NBG, int NA>
-__global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
+template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int NBG, int NA, int GPT = 1>
+__global__ void __launch_bounds__(64 * ((H * GPT + 31) / 32) * WR)
 lstm_h2o_kernel(const LstmH2Args args) {
-  constexpr int NG = (H + 31) / 32;
+  static_assert(GPT == 1 || GPT == 2, "gates per tile");
+  constexpr int UPW = 32 / GPT, NGT = 4 / GPT;                 // hidden units per wave / accumulator tiles per row tile
+  constexpr int NG = (H + UPW - 1) / UPW;
   constexpr int KB0 = KQ0 / 4, KB1 = KQ1 / 4, KB_IN = KB0 + KB1, KB_REC = H / 16, KB = KB_IN + KB_REC;
   constexpr int ROWS = 32 * R * WR;
   constexpr int PLANE = ROWS * 4 + 4;
-  constexpr int HBUF = (NG * 32 / 4) * PLANE;
+  constexpr int HBUF = (NG * UPW / 4) * PLANE;
   constexpr int NTHREADS = 64 * NG * WR;
   constexpr int LBG = NBG - 1, LA = NA - 1;
   static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
-  static_assert((4 * KB) % NBG == 0 && (4 * KB_IN) % NBG == 0 && KB % NA == 0 && KB_IN % NA == 0,
+  static_assert((NGT * KB) % NBG == 0 && (NGT * KB_IN) % NBG == 0 && KB % NA == 0 && KB_IN % NA == 0,
                 "ring sizes must divide the block counts");
-  static_assert(LA >= 1 && LA <= KB_IN && LA <= KB_REC && LBG <= 4 * KB_REC, "leads must stay inside a phase");
+  static_assert(LA >= 1 && LA <= KB_IN && LA <= KB_REC && LBG <= NGT * KB_REC, "leads must stay inside a phase");
+  static_assert(H % UPW == 0, "hidden units per wave");
 
-  constexpr bool CLDS = R >= 2;
+  constexpr bool CLDS = R >= 2 && GPT == 1;
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
   __shared__ __attribute__((aligned(16))) float bnl[2 * H];
   __shared__ float cl[CLDS ? 16 * R * NTHREADS : 1];
 
+#if NRV_EXP & 64
+  const unsigned long long exp_c0 = clock64(), exp_w0 = wall_clock64();    // shader clock / 100 MHz
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hg = wave % NG, wr = wave / NG;
@@ -398,30 +416,34 @@ lstm_h2o_kernel(const LstmH2Args args) {
   const int lrow0 = wr * (32 * R);
 
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(
-      (const char*)P.wsplit + ((size_t)(dir * NG + hg) * KB) * (4 * 2 * 1024), KB * 4 * 2 * 1024);
+      (const char*)P.wsplit + ((size_t)(dir * NG + hg) * KB) * (NGT * 2 * 1024), KB * NGT * 2 * 1024);
   const unsigned wlane = lane * 16;
-  const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * 32 + l31;
+  const int ul = l31 % UPW;                                   // this lane's unit inside the wave's group
+  const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * UPW + ul;
   // The bias (x 2^E in memory) is not added to the accumulators - a pre-splatted 16-register tile per
   // gate would sit in the register file for the whole launch - it rides on the gate constants:
   //   hard_sigmoid(z) = clamp(acc * 0.2d + (0.5 + 0.2 b)),  tanh(z) from exp2(acc * 2log2e d + 2log2e b)
   const float dsc = P.descale, dsc02 = 0.2f * dsc, dsc2 = 2.885390081777927f * dsc;
-  const float bz[4] = {bp[0] * dsc, bp[32] * dsc, bp[64] * dsc, bp[96] * dsc};      // exact: d is a power of two
+  const float bz[4] = {bp[0] * dsc, bp[UPW] * dsc, bp[2 * UPW] * dsc, bp[3 * UPW] * dsc};      // exact: d is a power of two
   const float kI = __builtin_fmaf(bz[0], 0.2f, 0.5f), kF = __builtin_fmaf(bz[1], 0.2f, 0.5f),
               kO = __builtin_fmaf(bz[3], 0.2f, 0.5f), kG = bz[2] * 2.885390081777927f;
-  const int u = hg * 32 + l31;
-  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half) * 4;
+  const int u = hg * UPW + ul;
+  // rows of this lane's elements: accumulator register j -> (j & 3) + 8 (j >> 2) + 4 half; with two gates
+  // per tile lanes 16-31 take the registers 8-15 of their tile (16 rows further down) after the exchange
+  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half + (GPT == 2 ? 16 * (l31 >> 4) : 0)) * 4;
   const int hp_off = (2 * half) * PLANE + (lrow0 + l31) * 4;
 
   for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
     bnl[i] = i < H ? P.out_scale[dir * H + i] : P.out_shift[dir * H + i - H];
   for (int i = threadIdx.x; i < HBUF; i += NTHREADS) hbuf[i] = 0.f;          // image of h_{-1} (buffer 0)
-  f32x16 c[CLDS ? 1 : R];
+  constexpr int EPR = 16 / GPT, NE = EPR * R;                  // gate elements per lane: per row tile / in all
+  float c[CLDS ? 1 : NE];
   if constexpr (CLDS) {
 #pragma unroll
     for (int i = 0; i < 16 * R; ++i) cl[i * NTHREADS + threadIdx.x] = 0.f;
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
+    for (int i = 0; i < NE; ++i) c[i] = 0.f;
   }
   __syncthreads();
 
@@ -451,12 +473,21 @@ lstm_h2o_kernel(const LstmH2Args args) {
   struct AReg { f32x4 v[2]; };
   BReg b[NBG];
   AReg a[NA][R];
-  // weight entry e = 4*kb + g over the step's block sequence (input blocks, then recurrent blocks)
+#if NRV_EXP
+  bool exp_steady = false;      // experiments (tools/lstm_exp.sh): requests compiled out behind the prologue
+#endif
+  // weight entry e = NGT*kb + g over the step's block sequence (input blocks, then recurrent blocks)
   auto loadB = [&](int e, BReg& bb) __attribute__((always_inline)) {
+#if NRV_EXP & 2
+    if (exp_steady) return;
+#endif
     bb.t[0] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2) * 1024));
     bb.t[1] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + 1) * 1024));
   };
   auto loadA_in = [&](const ABase& ab, int kb, int r, AReg& d) __attribute__((always_inline)) {
+#if NRV_EXP & 4
+    if (exp_steady) return;
+#endif
     if (KQ1 == 0 || kb < KB0) {
       d.v[0] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048);
       d.v[1] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048 + 1024);
@@ -466,6 +497,9 @@ lstm_h2o_kernel(const LstmH2Args args) {
     }
   };
   auto loadA_rec = [&](const float* hp, int kbr, int r, AReg& d) __attribute__((always_inline)) {
+#if NRV_EXP & 4
+    if (exp_steady) return;
+#endif
     const float* qh = hp + kbr * 4 * PLANE + r * 128;
     d.v[0] = *(const f32x4*)(qh);
     d.v[1] = *(const f32x4*)(qh + PLANE);
@@ -477,15 +511,26 @@ lstm_h2o_kernel(const LstmH2Args args) {
   // free, what exceeds them delays the next MFMA (the wave issues in order).  hipcc's scheduler does
   // not spread a dependent chain (one gate element is ~25 dependent instructions) between MFMAs by
   // itself, so the chains are cut by hand into stages, one stage per MFMA "tick", each tick fenced.
-  constexpr int NE = 16 * R;                                   // gate elements per lane
   constexpr int GST = 6;                                       // stages of one gate element
   struct GateSt { float zi, zf, zg, zo, cp, p, hv; };
-  auto gate_stage = [&](GateSt& g, const f32x16 (&Z)[4][R], float* hw, int e, int st) __attribute__((always_inline)) {
-    const int r = e / 16, reg = e % 16;
+  auto gate_stage = [&](GateSt& g, const f32x16 (&Z)[NGT][R], float* hw, int e, int st) __attribute__((always_inline)) {
+    const int r = e / EPR, reg = e % EPR;
     if (st == 0) {
-      g.zi = Z[0][r][reg]; g.zf = Z[1][r][reg]; g.zg = Z[2][r][reg]; g.zo = Z[3][r][reg];
+      if constexpr (GPT == 1) {
+        g.zi = Z[0][r][reg]; g.zf = Z[1][r][reg]; g.zg = Z[2][r][reg]; g.zo = Z[3][r][reg];
+      } else {
+        // register j of a tile holds [gate a | gate b] of rows(j), register 8+j the same of rows(j) + 16:
+        // swapping lanes 16-31 of the first with lanes 0-15 of the second leaves (a, b) of one row set per lane
+        // (scalars first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
+        const float a0 = Z[0][r][reg], b0 = Z[0][r][8 + reg], a1 = Z[1][r][reg], b1 = Z[1][r][8 + reg];
+        const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+        const unsigned ui = s0[0], uf = s0[1], ug = s1[0], uo = s1[1];
+        g.zi = __builtin_bit_cast(float, ui); g.zf = __builtin_bit_cast(float, uf);
+        g.zg = __builtin_bit_cast(float, ug); g.zo = __builtin_bit_cast(float, uo);
+      }
       if constexpr (CLDS) g.cp = cl[e * NTHREADS + threadIdx.x];
-      else g.cp = c[r][reg];
+      else g.cp = c[e];
     } else if (st == 1) {
       if constexpr (ACT == 0) {
         g.zi = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(g.zi, dsc02, kI), 0.0f), 1.0f);
@@ -503,7 +548,7 @@ lstm_h2o_kernel(const LstmH2Args args) {
     } else if (st == 3) {
       const float cn = __builtin_fmaf(g.zf, g.cp, g.p);
       if constexpr (CLDS) cl[e * NTHREADS + threadIdx.x] = cn;
-      else c[r][reg] = cn;
+      else c[e] = cn;
       g.zg = __builtin_amdgcn_exp2f(cn * 2.885390081777927f);
     } else if (st == 4) {
       // og * tanh(c) * 2^13, the scale riding on tanh's last fma
@@ -574,14 +619,14 @@ lstm_h2o_kernel(const LstmH2Args args) {
   // stages of Z occupy the ticks [0, TG), the barrier follows tick TG - 1, the copy-out stages of the
   // finished image take the ticks behind it.  WORK = false: the prologue (no Z yet).
   // hp_next: image the following rec() reads; its first LA blocks are requested here, behind the barrier.
-  constexpr int NTICK = KB_IN * 4 * 3 * R;
+  constexpr int NTICK = KB_IN * NGT * 3 * R;
   constexpr int NGP = NE * GST, NCP = NIT * CST;               // pieces
   constexpr int TG_WANT = NGP < (2 * NTICK) / 3 ? NGP : (2 * NTICK) / 3;
-  constexpr int TG_MAX = (KB_IN - LA) * 4 * 3 * R;             // the rec() operands are requested from block KB_IN - LA on
+  constexpr int TG_MAX = (KB_IN - LA) * NGT * 3 * R;             // the rec() operands are requested from block KB_IN - LA on
   constexpr int TG = TG_WANT < TG_MAX ? TG_WANT : TG_MAX;
   constexpr int TC = NTICK - TG;
   static_assert(TG >= 1 && TC >= 1, "no room for the gates / copy-out in the input phase");
-  auto in_phase = [&](auto work_tag, f32x16 (&N)[4][R], const f32x16 (&Z)[4][R], const ABase& xb,
+  auto in_phase = [&](auto work_tag, f32x16 (&N)[NGT][R], const f32x16 (&Z)[NGT][R], const ABase& xb,
                       const float* hp_next, float* himg_w, int t_out, const ABase& xb_wrap) __attribute__((always_inline)) {
     // WORK = false is the prologue, in(0): step 0 has no recurrent blocks (h_{-1} = 0), so what follows
     // it is in(1), and its tail requests wrap around to the input blocks / weights of step 1 (xb_wrap)
@@ -589,7 +634,7 @@ lstm_h2o_kernel(const LstmH2Args args) {
     GateSt gs;
     CopySt cs;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < NGT; ++g)
 #pragma unroll
       for (int r = 0; r < R; ++r) N[g][r] = splat16(0.0f);
 #pragma unroll
@@ -604,9 +649,9 @@ lstm_h2o_kernel(const LstmH2Args args) {
         }
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int e = 4 * kb + g;
-        loadB(WORK ? (e + LBG) % (4 * KB) : (e + LBG) % (4 * KB_IN), b[(e + LBG) % NBG]);
+      for (int g = 0; g < NGT; ++g) {
+        const int e = NGT * kb + g;
+        loadB(WORK ? (e + LBG) % (NGT * KB) : (e + LBG) % (NGT * KB_IN), b[(e + LBG) % NBG]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -615,11 +660,15 @@ lstm_h2o_kernel(const LstmH2Args args) {
             const int tk = (e * R + r) * 3 + pr;
             N[g][r] = mfma_f16(__builtin_bit_cast(f16x8, a[kb % NA][r].v[PA[pr]]), b[e % NBG].t[PB[pr]], N[g][r]);
             if constexpr (WORK) {
+#if NRV_EXP & 1
+              if (false) {
+#else
               if (tk < TG) {
+#endif
 #pragma unroll
                 for (int pc = (tk * NGP) / TG; pc < ((tk + 1) * NGP) / TG; ++pc)
                   gate_stage(gs, Z, himg_w + hw_off, pc / GST, pc % GST);
-              } else {
+              } else if (!(NRV_EXP & 1)) {
 #pragma unroll
                 for (int pc = ((tk - TG) * NCP) / TC; pc < ((tk - TG + 1) * NCP) / TC; ++pc)
                   copy_stage(cs, himg_w, t_out, pc / CST, pc % CST);
@@ -635,10 +684,37 @@ lstm_h2o_kernel(const LstmH2Args args) {
   // ---- rec(): Z += h U over the recurrent blocks of the image at hp; the split of the next block's
   // units runs in the shadow of this block's MFMAs.  The first LA input blocks of the in() phase that
   // follows (bases xb_next) are requested here.
-  auto rec_phase = [&](f32x16 (&Z)[4][R], const float* hp, const ABase& xb_next) __attribute__((always_inline)) {
+  auto rec_phase = [&](f32x16 (&Z)[NGT][R], const float* hp, const ABase& xb_next) __attribute__((always_inline)) {
     Split2 sp[2][R];
+    // the split of one block, cut like the gates: two values of one row tile go through three stages
+    // (hi terms; residuals; lo terms), one stage per MFMA tick: 4R pairs over the block's 12R ticks
+    constexpr int NSP = 3 * 4 * R, NTK = NGT * 3 * R;          // stage pieces / MFMA ticks per k-block
+    struct SplitSt { float d0, d1; };
+    SplitSt ss;
+    auto split_piece = [&](Split2& o, const AReg& src, int j0, int st) __attribute__((always_inline)) {
+#if NRV_EXP & 8
+      if (j0 == 0 && st == 0) { o.t[0] = __builtin_bit_cast(f16x8, src.v[0]); o.t[1] = __builtin_bit_cast(f16x8, src.v[1]); }
+#else
+      const float x0 = j0 < 4 ? src.v[0][j0] : src.v[1][j0 - 4], x1 = j0 < 4 ? src.v[0][j0 + 1] : src.v[1][j0 - 3];
+      if (st == 0) {
+        o.t[0][j0] = (_Float16)x0;
+        o.t[0][j0 + 1] = (_Float16)x1;
+      } else if (st == 1) {
+        ss.d0 = x0 - (float)o.t[0][j0];
+        ss.d1 = x1 - (float)o.t[0][j0 + 1];
+      } else {
+        o.t[1][j0] = (_Float16)ss.d0;
+        o.t[1][j0 + 1] = (_Float16)ss.d1;
+      }
+#endif
+    };
 #pragma unroll
-    for (int r = 0; r < R; ++r) sp[0][r] = split2(a[KB_IN % NA][r].v[0], a[KB_IN % NA][r].v[1]);
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j0 = 0; j0 < 8; j0 += 2)
+#pragma unroll
+        for (int st = 0; st < 3; ++st) split_piece(sp[0][r], a[KB_IN % NA][r], j0, st);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kr = 0; kr < KB_REC; ++kr) {
       const int kb = KB_IN + kr;
@@ -650,32 +726,25 @@ lstm_h2o_kernel(const LstmH2Args args) {
           else loadA_in(xb_next, ka - KB, r, a[ka % NA][r]);
         }
       }
-      if (kr + 1 < KB_REC) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) sp[(kr + 1) & 1][r] = split2(a[(kb + 1) % NA][r].v[0], a[(kb + 1) % NA][r].v[1]);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int e = 4 * kb + g;
-        loadB((e + LBG) % (4 * KB), b[(e + LBG) % NBG]);
+      for (int g = 0; g < NGT; ++g) {
+        const int e = NGT * kb + g;
+        loadB((e + LBG) % (NGT * KB), b[(e + LBG) % NBG]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-          for (int pr = 0; pr < 3; ++pr)
+          for (int pr = 0; pr < 3; ++pr) {
+            const int tk = (g * R + r) * 3 + pr;
             Z[g][r] = mfma_f16(sp[kr & 1][r].t[PA[pr]], b[e % NBG].t[PB[pr]], Z[g][r]);
-      }
-      // one scheduling region per k-block: [A refill][per gate: 2 weight loads, 3R x (MFMA, 2 split ops)]
-      __builtin_amdgcn_sched_group_barrier(0x120, 2 * R, 0);
+            if (kr + 1 < KB_REC) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-#pragma unroll
-        for (int i = 0; i < 3 * R; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
+              for (int pc = (tk * NSP) / NTK; pc < ((tk + 1) * NSP) / NTK; ++pc)
+                split_piece(sp[(kr + 1) & 1][pc / 12], a[(kb + 1) % NA][pc / 12], 2 * ((pc / 3) % 4), pc % 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -683,7 +752,7 @@ lstm_h2o_kernel(const LstmH2Args args) {
   // moved into Z (128 v_accvgpr_mov at R = 2, ~3 % of a step).  Alternating the roles of two sets in a
   // body unrolled x2 avoids the moves on paper, but hipcc then cannot keep either set in place across
   // the loop edge (it inserted more moves than this, plus 64 spilled registers).
-  f32x16 Z[4][R], N[4][R];
+  f32x16 Z[NGT][R], N[NGT][R];
   auto himg = [&](int s) __attribute__((always_inline)) { return hbuf + ((s + 1) & 1) * HBUF; };   // image of h_s
   auto t_of = [&](int s) __attribute__((always_inline)) { return dir ? (T - 1 - s) : s; };
 
@@ -691,13 +760,16 @@ lstm_h2o_kernel(const LstmH2Args args) {
   {
     const ABase x0 = mk_base(0), x1 = mk_base(1);
 #pragma unroll
-    for (int e = 0; e < LBG; ++e) loadB(e % (4 * KB_IN), b[e]);
+    for (int e = 0; e < LBG; ++e) loadB(e % (NGT * KB_IN), b[e]);
 #pragma unroll
     for (int i = 0; i < LA; ++i)
 #pragma unroll
       for (int r = 0; r < R; ++r) loadA_in(x0, i, r, a[i][r]);
     in_phase(std::false_type{}, Z, Z, x0, nullptr, nullptr, 0, x1);
   }
+#if NRV_EXP
+  exp_steady = true;
+#endif
 #pragma unroll 1
   for (int s = 0; s < T; ++s) {
     // step s: Z holds x_s W on entry; on exit it holds x_{s+1} W and h_s has been written out
@@ -706,7 +778,7 @@ lstm_h2o_kernel(const LstmH2Args args) {
     if (s + 1 < T) {
       in_phase(std::true_type{}, N, Z, xn, himg(s) + hp_off, himg(s), t_of(s), xn);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < NGT; ++g)
 #pragma unroll
         for (int r = 0; r < R; ++r) Z[g][r] = N[g][r];
     } else {
@@ -726,6 +798,10 @@ lstm_h2o_kernel(const LstmH2Args args) {
         for (int st = 0; st < CST; ++st) copy_stage(cs, himg(s), t_of(s), i, st);
     }
   }
+#if NRV_EXP & 64
+  if (blockIdx.x == 3 && threadIdx.x == 0 && ((NRV_EXP & 128) ? (H == 64 && KQ0 == 64) : H == 128))
+    printf("CLK %llu %llu\n", (unsigned long long)(clock64() - exp_c0), (unsigned long long)(wall_clock64() - exp_w0));
+#endif
 }
 
 }  // namespace nrv

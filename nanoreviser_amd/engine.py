@@ -97,7 +97,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("NRV_LIB") or LIB_PATH        # NRV_LIB: another build of the same ABI
     if not os.path.exists(p):
         raise OSError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
