@@ -488,12 +488,13 @@ lstm_h2o_kernel(const LstmH2Args args) {
 #if NRV_EXP & 4
     if (exp_steady) return;
 #endif
+    // the lo term first: the block's first product takes the hi term, so ONE counted wait covers both
     if (KQ1 == 0 || kb < KB0) {
-      d.v[0] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048);
       d.v[1] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048 + 1024);
+      d.v[0] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048);
     } else {
-      d.v[0] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048);
       d.v[1] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048 + 1024);
+      d.v[0] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048);
     }
   };
   auto loadA_rec = [&](const float* hp, int kbr, int r, AReg& d) __attribute__((always_inline)) {
@@ -504,7 +505,8 @@ lstm_h2o_kernel(const LstmH2Args args) {
     d.v[0] = *(const f32x4*)(qh);
     d.v[1] = *(const f32x4*)(qh + PLANE);
   };
-  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};          // lo*hi, hi*lo, hi*hi
+  // hi*lo, lo*hi, hi*hi: the first product of an entry takes the LAST-requested fragment of both operands
+  constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 
   // ---- the VALU work of a step, cut into PIECES of at most ~5 instructions ------------------------
   // An MFMA holds the SIMD's issue port for 8 of its 32 cycles; what a wave issues in the other 24 is
