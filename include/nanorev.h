@@ -102,7 +102,10 @@ int nrv_predict_device(nrv_handle* h, const float* d_signal, const float* d_read
 int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d_feat_ev,
                             int64_t N, float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2);
 
-/* Windows per internal launch group (Keras' predict(batch_size=...)); default 4096. */
+/* Windows per internal launch group (Keras' predict(batch_size=...)); default 4096.  Results do not
+ * depend on the grouping.  With groups of <= 2048 windows the device-pointer entry points run consecutive
+ * groups concurrently on several streams (each with its own activation buffers), joined on the handle's
+ * stream before the call returns. */
 int nrv_set_batch(nrv_handle* h, int batch_windows);
 int nrv_get_batch(nrv_handle* h);
 

@@ -448,6 +448,17 @@ struct nrv_handle {
   // workspace (per model)
   int cap_rows = 0;                // padded rows the workspace holds
   float *S[2] = {0, 0}, *X1[2] = {0, 0}, *X2[2] = {0, 0}, *X3[2] = {0, 0}, *MO[2] = {0, 0};
+  // Lanes: a launch group of <= 2048 windows leaves most of the 256 CUs idle (512 windows = 32 workgroups per
+  // Bi-LSTM launch), so the device-pointer entry points run consecutive groups on up to kMaxLanes streams,
+  // each with its own activation buffers; results do not depend on the grouping.  NRV_LANES=0 turns it off.
+  static constexpr int kMaxLanes = 8;
+  struct Lane {
+    float *S[2] = {0, 0}, *X1[2] = {0, 0}, *X2[2] = {0, 0}, *X3[2] = {0, 0}, *MO[2] = {0, 0};
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+  } lanes[kMaxLanes];
+  int n_lanes = 0, lane_rows = 0, lanes_on = 1;
+  hipEvent_t ev_fork = nullptr;
   // staging for the host-pointer entry points
   // two staging sets [set][..]: the upload of group g+1 (copy stream) overlaps the kernels of group g
   float *d_sig[2] = {0, 0}, *d_feat[2] = {0, 0}, *d_p[2][2] = {{0, 0}, {0, 0}};
@@ -677,6 +688,54 @@ static int ensure_workspace(nrv_handle* h) {
     HIPCHK(h, hipHostMalloc((void**)&h->pin_out[st], (size_t)rows * kOutBytes, hipHostMallocDefault));
   }
   h->cap_rows = rows;
+  return NRV_OK;
+}
+
+static void free_lanes(nrv_handle* h) {
+  for (int l = 0; l < nrv_handle::kMaxLanes; ++l) {
+    nrv_handle::Lane& L = h->lanes[l];
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    for (int m = 0; m < 2; ++m) {
+      (void)hipFree(L.S[m]); (void)hipFree(L.X1[m]); (void)hipFree(L.X2[m]); (void)hipFree(L.X3[m]); (void)hipFree(L.MO[m]);
+      L.S[m] = L.X1[m] = L.X2[m] = L.X3[m] = L.MO[m] = nullptr;
+    }
+  }
+  h->n_lanes = 0;
+  h->lane_rows = 0;
+}
+
+// Lanes for the current batch: 4096 / batch of them (2 .. kMaxLanes) when a group is <= 2048 windows.
+static int ensure_lanes(nrv_handle* h) {
+  const int T = h->T;
+  const int rows = ((h->batch + kRowPad - 1) / kRowPad) * kRowPad;
+  int want = 0;
+  if (h->lanes_on && h->batch <= 2048) {
+    want = 4096 / h->batch;
+    if (want > nrv_handle::kMaxLanes) want = nrv_handle::kMaxLanes;
+  }
+  if (want == h->n_lanes && (want == 0 || rows <= h->lane_rows)) return NRV_OK;
+  free_lanes(h);
+  if (want == 0) return NRV_OK;
+  const size_t tiles = rows / 32;
+  const size_t nS = (tiles * T + 2) * 16 * 128, n1 = tiles * T * 8 * 128, n2 = tiles * T * 32 * 128,
+               n3 = tiles * T * 64 * 128, nm = tiles * T * 256;
+  if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  for (int l = 0; l < want; ++l) {
+    nrv_handle::Lane& L = h->lanes[l];
+    if (!L.stream) HIPCHK(h, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    if (!L.done) HIPCHK(h, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    for (int m = 0; m < 2; ++m) {
+      float** bufs[5] = {&L.S[m], &L.X1[m], &L.X2[m], &L.X3[m], &L.MO[m]};
+      const size_t sz[5] = {nS, n1, n2, n3, nm};
+      for (int i = 0; i < 5; ++i) {
+        HIPCHK(h, hipMalloc(bufs[i], sz[i] * 4));
+        HIPCHK(h, hipMemset(*bufs[i], 0, sz[i] * 4));
+      }
+    }
+  }
+  HIPCHK(h, hipDeviceSynchronize());
+  h->n_lanes = want;
+  h->lane_rows = rows;
   return NRV_OK;
 }
 
@@ -1017,6 +1076,7 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
          hipEventCreateWithFlags(&h->ev_done[st], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_out[st], hipEventDisableTiming) == hipSuccess;
   if (const char* e2 = getenv("NRV_HOST_REGISTER")) h->host_register = atoi(e2) != 0;
+  if (const char* e3 = getenv("NRV_LANES")) h->lanes_on = atoi(e3) != 0;
   if (!ok) { g_create_error = "nrv_create: could not create the copy stream / events"; nrv_destroy(h); return NRV_E_HIP; }
   if ((rc = upload_model(h, 0, b1, 6)) || (rc = upload_model(h, 1, b2, 5)) || (rc = ensure_workspace(h))) {
     g_create_error = h->err;
@@ -1032,6 +1092,12 @@ void nrv_destroy(nrv_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_workspace(h);
+  free_lanes(h);
+  for (int l = 0; l < nrv_handle::kMaxLanes; ++l) {
+    if (h->lanes[l].done) (void)hipEventDestroy(h->lanes[l].done);
+    if (h->lanes[l].stream) (void)hipStreamDestroy(h->lanes[l].stream);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int m = 0; m < 2; ++m) (void)hipFree(h->dm[m].all);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -1053,7 +1119,8 @@ int nrv_set_batch(nrv_handle* h, int batch) {
   if (batch < 1 || batch > (1 << 20)) { h->err = "nrv_set_batch: batch out of range"; return NRV_E_INVALID; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->batch = batch;
-  return ensure_workspace(h);
+  if ((rc = ensure_workspace(h))) return rc;
+  return ensure_lanes(h);
 }
 int nrv_get_batch(nrv_handle* h) { return h ? h->batch : NRV_E_INVALID; }
 
@@ -1088,20 +1155,62 @@ int nrv_sync(nrv_handle* h) {
   return NRV_OK;
 }
 
+}  // extern "C"
+
+// The launch groups of a device-pointer call: in order on the handle's stream, or - small groups -
+// round-robin over the lanes: every lane stream starts behind what the handle's stream holds at entry
+// (the caller's inputs) and the handle's stream ends behind every lane.  body(first window, windows).
+template <class F>
+static int for_groups(nrv_handle* h, int64_t n, F&& body) {
+  const int64_t ng = (n + h->batch - 1) / h->batch;
+  int nl = (h->n_lanes > 1 && ng > 1 && h->prof == 0) ? h->n_lanes : 0;
+  if ((int64_t)nl > ng) nl = (int)ng;
+  hipStream_t main = h->stream;
+  float* keep[5][2];
+  for (int m = 0; m < 2; ++m) { keep[0][m] = h->S[m]; keep[1][m] = h->X1[m]; keep[2][m] = h->X2[m]; keep[3][m] = h->X3[m]; keep[4][m] = h->MO[m]; }
+  auto restore = [&]() {
+    for (int m = 0; m < 2; ++m) { h->S[m] = keep[0][m]; h->X1[m] = keep[1][m]; h->X2[m] = keep[2][m]; h->X3[m] = keep[3][m]; h->MO[m] = keep[4][m]; }
+    h->stream = main;
+  };
+  if (nl) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, main));
+    for (int l = 0; l < nl; ++l) HIPCHK(h, hipStreamWaitEvent(h->lanes[l].stream, h->ev_fork, 0));
+  }
+  int rc = NRV_OK;
+  int64_t g = 0;
+  for (int64_t s = 0; s < n && !rc; s += h->batch, ++g) {
+    const int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+    if (nl) {
+      const nrv_handle::Lane& L = h->lanes[g % nl];
+      for (int m = 0; m < 2; ++m) { h->S[m] = L.S[m]; h->X1[m] = L.X1[m]; h->X2[m] = L.X2[m]; h->X3[m] = L.X3[m]; h->MO[m] = L.MO[m]; }
+      h->stream = L.stream;
+    }
+    rc = body(s, nb);
+  }
+  restore();
+  if (nl) {
+    for (int l = 0; l < nl; ++l) {
+      hipError_t e = hipEventRecord(h->lanes[l].done, h->lanes[l].stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(main, h->lanes[l].done, 0);
+      if (e != hipSuccess && !rc) { h->err = std::string("lane join: ") + hipGetErrorString(e); rc = NRV_E_HIP; }
+    }
+  }
+  return rc;
+}
+
+extern "C" {
+
 int nrv_predict_device(nrv_handle* h, const float* d_signal, const float* d_read, int64_t n,
                        float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (n < 0 || (n > 0 && (!d_signal || !d_read))) { h->err = "nrv_predict_device: bad arguments"; return NRV_E_INVALID; }
   const int T = h->T;
-  for (int64_t s = 0; s < n; s += h->batch) {
-    int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
-    rc = run_group(h, d_signal + s * T * kSig, d_read + s * T * kFeat, nb, false,
-                   d_p1 ? d_p1 + s * 6 : nullptr, d_p2 ? d_p2 + s * 5 : nullptr,
-                   d_a1 ? d_a1 + s : nullptr, d_a2 ? d_a2 + s : nullptr);
-    if (rc) return rc;
-  }
-  return NRV_OK;
+  return for_groups(h, n, [&](int64_t s, int nb) {
+    return run_group(h, d_signal + s * T * kSig, d_read + s * T * kFeat, nb, false,
+                     d_p1 ? d_p1 + s * 6 : nullptr, d_p2 ? d_p2 + s * 5 : nullptr,
+                     d_a1 ? d_a1 + s : nullptr, d_a2 ? d_a2 + s : nullptr);
+  });
 }
 
 int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d_feat_ev, int64_t N,
@@ -1111,14 +1220,11 @@ int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d
   if (N < 0 || (N > 0 && (!d_sig_ev || !d_feat_ev))) { h->err = "nrv_predict_read_device: bad arguments"; return NRV_E_INVALID; }
   const int T = h->T;
   const int64_t n = N - T;
-  for (int64_t s = 0; s < n; s += h->batch) {
-    int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
-    rc = run_group(h, d_sig_ev + s * kSig, d_feat_ev + s * kFeat, nb, true,
-                   d_p1 ? d_p1 + s * 6 : nullptr, d_p2 ? d_p2 + s * 5 : nullptr,
-                   d_a1 ? d_a1 + s : nullptr, d_a2 ? d_a2 + s : nullptr);
-    if (rc) return rc;
-  }
-  return NRV_OK;
+  return for_groups(h, n, [&](int64_t s, int nb) {
+    return run_group(h, d_sig_ev + s * kSig, d_feat_ev + s * kFeat, nb, true,
+                     d_p1 ? d_p1 + s * 6 : nullptr, d_p2 ? d_p2 + s * 5 : nullptr,
+                     d_a1 ? d_a1 + s : nullptr, d_a2 ? d_a2 + s : nullptr);
+  });
 }
 
 // ---- raw-read path: upload samples / starts / descriptors once per call, cut windows per group ----

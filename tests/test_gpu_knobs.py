@@ -1,0 +1,48 @@
+"""The alternative kernels behind the environment knobs of DESIGN.md §3 stay parity-green: each knob is read
+once per process, so every case runs in its own interpreter (GPU box only)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from conftest import load_read
+from nanoreviser_amd import hoststage as hs
+from nanoreviser_amd.engine import Reviser
+from nanoreviser_amd.weights import load_species
+mg = np.load(os.path.join({root!r}, "tests", "golden", "model_goldens.npz"))
+out = {{}}
+for sp in ("ecoli", "human"):
+    m1, m2 = load_species(sp)
+    rv = Reviser(m1, m2, precision="f16x2")
+    key = "ch10_read5252"
+    _, _, rt = load_read(key)
+    sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, 11)
+    idx = mg[key + "/idx"]
+    p1, p2, a1, a2 = rv.predict_pair(np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx]))
+    out[sp] = dict(dp1=float(np.abs(p1 - mg[f"{{key}}/{{sp}}/p1"]).max()), dp2=float(np.abs(p2 - mg[f"{{key}}/{{sp}}/p2"]).max()),
+                   flips=int((a1 != mg[f"{{key}}/{{sp}}/a1"]).sum() + (a2 != mg[f"{{key}}/{{sp}}/a2"]).sum()))
+    rv.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["NRV_HT=0", "NRV_H2V=1", "NRV_CNNV=1"])
+def test_alternative_kernels_match_the_goldens(knob):
+    name, val = knob.split("=")
+    env = dict(os.environ, **{name: val})
+    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    for sp, d in res.items():
+        assert d["flips"] == 0, (knob, sp, d)
+        assert d["dp1"] <= 1e-4 and d["dp2"] <= 1e-4, (knob, sp, d)

@@ -382,6 +382,48 @@ def test_full_size_properties_device_api(species_models, sp):
     rv.close()
 
 
+def test_small_groups_run_on_lanes_bit_identical(species_models, monkeypatch):
+    """Launch groups of <= 2048 windows are spread over stream lanes with their own activation buffers
+    (nrv_api.hip for_groups): window and read mode, ragged tail, repeated calls - bit-identical to groups
+    of 4096 on one stream and to the same grouping with NRV_LANES=0."""
+    import torch
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["ecoli"]
+    T, n, N = 11, 10_037, 30_011
+    g = torch.Generator(device="cuda").manual_seed(77)
+    sig = (torch.randn(n, T, 50, device="cuda", generator=g) * 1.36 - 0.10).clamp_(-8.4, 4.8)
+    feat = torch.rand(n, T, 6, device="cuda", generator=g)
+    sig_ev = (torch.randn(N, 50, device="cuda", generator=g) * 1.36 - 0.10).clamp_(-8.4, 4.8)
+    feat_ev = torch.rand(N, 6, device="cuda", generator=g)
+
+    def outs(k):
+        return (torch.empty(k, 6, device="cuda"), torch.empty(k, 5, device="cuda"),
+                torch.empty(k, dtype=torch.int8, device="cuda"), torch.empty(k, dtype=torch.int8, device="cuda"))
+
+    def run(rv):
+        w, r = outs(n), outs(N - T)
+        rv.predict_device(sig.data_ptr(), feat.data_ptr(), n, *[x.data_ptr() for x in w])
+        rv.predict_read_device(sig_ev.data_ptr(), feat_ev.data_ptr(), N, *[x.data_ptr() for x in r])
+        rv.sync()
+        torch.cuda.synchronize()
+        return w + r
+
+    ref_rv = Reviser(m1, m2, batch=4096)
+    ref = run(ref_rv)
+    ref_rv.close()
+    for batch in (512, 1000, 2048):
+        rv = Reviser(m1, m2, batch=batch)
+        for _ in range(2):
+            for x, y in zip(ref, run(rv)):
+                assert torch.equal(x, y), batch
+        rv.close()
+    monkeypatch.setenv("NRV_LANES", "0")
+    rv = Reviser(m1, m2, batch=512)
+    for x, y in zip(ref, run(rv)):
+        assert torch.equal(x, y)
+    rv.close()
+
+
 @pytest.mark.parametrize("T", [1, 2, 5, 16, 32])
 def test_other_window_lengths_vs_oracle(species_models, T):
     """The engine is parametric in T (1..32); only `feature.kernel` depends on T, so
