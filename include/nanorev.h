@@ -103,9 +103,9 @@ int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d
                             int64_t N, float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2);
 
 /* Windows per internal launch group (Keras' predict(batch_size=...)); default 4096.  Results do not
- * depend on the grouping.  With groups of <= 2048 windows the device-pointer entry points run consecutive
- * groups concurrently on several streams (each with its own activation buffers), joined on the handle's
- * stream before the call returns. */
+ * depend on the grouping.  Groups of <= 2048 windows (whole row tiles: batch % 32 == 0) run concurrently on
+ * several streams, each with its own activation buffers, joined on the handle's stream before a call
+ * returns; the host-pointer entry points then move 4096 / batch groups per upload / download. */
 int nrv_set_batch(nrv_handle* h, int batch_windows);
 int nrv_get_batch(nrv_handle* h);
 

@@ -657,9 +657,21 @@ static void free_workspace(nrv_handle* h) {
   h->cap_rows = 0;
 }
 
+// Lanes the current batch asks for: 4096 / batch (2 .. kMaxLanes) when a group is <= 2048 windows.
+static int lanes_wanted(const nrv_handle* h) {
+  if (!h->lanes_on || h->batch > 2048 || h->batch % 32) return 0;      // whole row tiles only
+  const int w = 4096 / h->batch;
+  return w > nrv_handle::kMaxLanes ? nrv_handle::kMaxLanes : w;
+}
+// Windows per pipeline stage of the host-pointer entry points (one upload, its groups, one download).
+static int stage_windows(const nrv_handle* h) {
+  const int w = lanes_wanted(h);
+  return w > 1 ? w * h->batch : h->batch;
+}
+
 static int ensure_workspace(nrv_handle* h) {
   const int T = h->T;
-  int rows = ((h->batch + kRowPad - 1) / kRowPad) * kRowPad;
+  int rows = ((stage_windows(h) + kRowPad - 1) / kRowPad) * kRowPad;
   if (rows <= h->cap_rows) return NRV_OK;
   free_workspace(h);
   const size_t tiles = rows / 32;
@@ -704,15 +716,10 @@ static void free_lanes(nrv_handle* h) {
   h->lane_rows = 0;
 }
 
-// Lanes for the current batch: 4096 / batch of them (2 .. kMaxLanes) when a group is <= 2048 windows.
 static int ensure_lanes(nrv_handle* h) {
   const int T = h->T;
   const int rows = ((h->batch + kRowPad - 1) / kRowPad) * kRowPad;
-  int want = 0;
-  if (h->lanes_on && h->batch <= 2048) {
-    want = 4096 / h->batch;
-    if (want > nrv_handle::kMaxLanes) want = nrv_handle::kMaxLanes;
-  }
+  const int want = lanes_wanted(h);
   if (want == h->n_lanes && (want == 0 || rows <= h->lane_rows)) return NRV_OK;
   free_lanes(h);
   if (want == 0) return NRV_OK;
@@ -1338,7 +1345,9 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   HostPin pin_s, pin_f;
   const bool direct_s = !raw_reads && pin_s.pin(h, sig, ev_all * kSig * 4);
   const bool direct_f = pin_f.pin(h, feat, ev_all * kFeat * 4);
-  const size_t ev_grp = read_mode ? (size_t)(h->batch + T - 1) : (size_t)h->batch * T;
+  // a pipeline stage = one upload, its launch groups (on the lanes when groups are small), one download
+  const int stage = stage_windows(h);
+  const size_t ev_grp = read_mode ? (size_t)(stage + T - 1) : (size_t)stage * T;
   if (!raw_reads && !direct_s && (rc = grow_pinned(h, h->pin_sig, &h->pin_sig_cap, ev_grp * kSig * 4))) return rc;
   if (!direct_f && (rc = grow_pinned(h, h->pin_feat, &h->pin_feat_cap, ev_grp * kFeat * 4))) return rc;
 
@@ -1354,9 +1363,9 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   };
   int64_t g = 0, prev_s = 0;
   int prev_nb = 0;
-  for (int64_t s = 0; s < n; s += h->batch, ++g) {
+  for (int64_t s = 0; s < n; s += stage, ++g) {
     const int st = (int)(g & 1);
-    const int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+    const int nb = (int)((n - s < stage) ? (n - s) : stage);
     const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
     const float* hs = raw_reads ? nullptr : sig + (read_mode ? s * kSig : s * T * kSig);
     const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
@@ -1380,8 +1389,11 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     HIPCHK(h, hipEventRecord(h->ev_in[st], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[st], 0));
     if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[st]);
-    rc = run_group(h, h->d_sig[st], h->d_feat[st], nb, read_mode, h->d_p[st][0], h->d_p[st][1],
-                   h->d_a[st][0], h->d_a[st][1]);
+    rc = for_groups(h, nb, [&](int64_t w, int nw) {
+      return run_group(h, h->d_sig[st] + (read_mode ? w * kSig : w * T * kSig),
+                       h->d_feat[st] + (read_mode ? w * kFeat : w * T * kFeat), nw, read_mode,
+                       h->d_p[st][0] + w * 6, h->d_p[st][1] + w * 5, h->d_a[st][0] + w, h->d_a[st][1] + w);
+    });
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev_done[st], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, h->ev_done[st], 0));

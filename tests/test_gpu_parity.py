@@ -411,7 +411,7 @@ def test_small_groups_run_on_lanes_bit_identical(species_models, monkeypatch):
     ref_rv = Reviser(m1, m2, batch=4096)
     ref = run(ref_rv)
     ref_rv.close()
-    for batch in (512, 1000, 2048):
+    for batch in (512, 992, 1000, 2048):              # 1000: not whole row tiles, stays on one stream
         rv = Reviser(m1, m2, batch=batch)
         for _ in range(2):
             for x, y in zip(ref, run(rv)):
