@@ -11,8 +11,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 m1, m2 = load_species("ecoli")
 worst, cases, t0 = 0.0, 0, time.time()
 while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 90:
-    T = int(rng.integers(1, 33)); n = int(rng.integers(1, 700)); batch = int(rng.choice([64, 96, 128, 500, 4096]))
-    prec = str(rng.choice(["bf16x3", "f32"])); act = str(rng.choice(["hard_sigmoid", "sigmoid"]))
+    T = int(rng.integers(1, 33)); n = int(rng.integers(1, 2500)); batch = int(rng.choice([32, 64, 96, 128, 500, 512, 1024, 4096]))
+    prec = str(rng.choice(["f16x2", "f16x2", "bf16x3", "f32"])); act = str(rng.choice(["hard_sigmoid", "sigmoid"]))
     a, b = m1.with_window(T), m2.with_window(T)
     sig, rd = O.synth_windows(n, T, seed=int(rng.integers(1 << 30)))
     rv = Reviser(a, b, precision=prec, recurrent_activation=act, batch=batch)
