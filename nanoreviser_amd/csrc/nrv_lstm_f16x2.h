@@ -2,6 +2,12 @@
 #pragma once
 #include "nrv_lstm_f32.h"
 
+// Experiment builds (tools/lstm_exp.sh, -DNRV_EXP=<bits>; 0 in the product): parts of lstm_h2o_kernel compiled
+// out - results WRONG by construction, only cycles / clock / time mean something, and even those only with
+// care: the chip's clock follows the kernel's power, which follows the DATA.
+//   1 no gate / copy-out pieces   2 no weight loads behind the prologue   4 no activation loads
+//   8 no split of the recurrent operand   64 device printf of clock64 / wall_clock64 deltas of workgroup 3
+//   (of the 192->128 layer; +128: the 256->64 layer; +256: the 32->64 layer) - scripts/gpu_clk.sh
 #ifndef NRV_EXP
 #define NRV_EXP 0
 #endif
@@ -801,7 +807,7 @@ lstm_h2o_kernel(const LstmH2Args args) {
     }
   }
 #if NRV_EXP & 64
-  if (blockIdx.x == 3 && threadIdx.x == 0 && ((NRV_EXP & 128) ? (H == 64 && KQ0 == 64) : H == 128))
+  if (blockIdx.x == 3 && threadIdx.x == 0 && ((NRV_EXP & 256) ? (H == 64 && KQ0 == 8) : (NRV_EXP & 128) ? (H == 64 && KQ0 == 64) : H == 128))
     printf("CLK %llu %llu\n", (unsigned long long)(clock64() - exp_c0), (unsigned long long)(wall_clock64() - exp_w0));
 #endif
 }
