@@ -271,6 +271,12 @@ def test_batch_grouping_is_invisible(reads, species_models):
     rv = Reviser(m1, m2)
     assert np.array_equal(rv.model1.predict([sw[..., None], fw]), outs[0][0])
     assert np.array_equal(rv.model2.predict([sw[..., None], fw], batch_size=512), outs[0][1])
+    # the facade's pair cache must not serve stale results after an in-place refill of the same arrays
+    s4, f4 = sw[..., None].copy(), fw.copy()
+    first = rv.model1.predict([s4, f4])
+    s4[:] = s4[::-1].copy(); f4[:] = f4[::-1].copy()
+    assert np.array_equal(rv.model2.predict([s4, f4]), outs[0][1][::-1])
+    assert np.array_equal(rv.model1.predict([s4, f4]), first[::-1])
     rv.close()
 
 
