@@ -801,7 +801,7 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA, int NBG, int NA, int GPT = 1>
+template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int LB, int LA, int NBG, int NA, int GPT = 1, int KBL = 0>
 static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
                            float* const out[2], int T, int n, int tiles) {
   constexpr int NG = (H * GPT + 31) / 32;
@@ -824,8 +824,8 @@ static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], co
       return;
     }
   }
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA, GPT>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT>), grid, blk, 0, h->stream, sa);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -958,7 +958,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2; split planes for head_h2_kernel
       // NRV_HT=0: one gate per accumulator tile (two pairs of waves, R = 1) instead of two (four waves, R = 2)
       static const bool ht = !(getenv("NRV_HT") && atoi(getenv("NRV_HT")) == 0);
-      if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2>(h, 3, i0, none, o, T, n, tiles);
+      // 7 of its 20 weight k-blocks stay in LDS (112 KB; the layer's other LDS use is 34 KB): -1.8 %
+      if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2, 7>(h, 3, i0, none, o, T, n, tiles);
       else launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};

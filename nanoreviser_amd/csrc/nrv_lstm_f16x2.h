@@ -383,7 +383,9 @@ lstm_h2_kernel(const LstmH2Args args) {
 // pair: lanes 0-15 end up with i, f, g, o of rows 0-3 / 8-11 of their unit, lanes 16-31 with rows 16-19 /
 // 24-27 (+4 in the upper half of the wave).
 // ---------------------------------------------------------------------------------------
-template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int NBG, int NA, int GPT = 1>
+// KBL: the weight fragments of the first KBL input blocks stay in LDS for the whole launch (each wave its own
+// 2 NGT KBL KB, copied once in the prologue) and enter the ring by ds_read instead of from L2.
+template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int NBG, int NA, int GPT = 1, int KBL = 0>
 __global__ void __launch_bounds__(64 * ((H * GPT + 31) / 32) * WR)
 lstm_h2o_kernel(const LstmH2Args args) {
   static_assert(GPT == 1 || GPT == 2, "gates per tile");
@@ -405,6 +407,8 @@ lstm_h2o_kernel(const LstmH2Args args) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
   __shared__ __attribute__((aligned(16))) float bnl[2 * H];
   __shared__ float cl[CLDS ? 16 * R * NTHREADS : 1];
+  constexpr int NWV = NG * WR;
+  __shared__ __attribute__((aligned(16))) float wl[KBL > 0 ? NWV * KBL * NGT * 512 : 4];
 
 #if NRV_EXP & 64
   const unsigned long long exp_c0 = clock64(), exp_w0 = wall_clock64();    // shader clock / 100 MHz
@@ -439,6 +443,19 @@ lstm_h2o_kernel(const LstmH2Args args) {
   const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half + (GPT == 2 ? 16 * (l31 >> 4) : 0)) * 4;
   const int hp_off = (2 * half) * PLANE + (lrow0 + l31) * 4;
 
+  float* const wlw = wl + (wave * KBL * NGT) * 512 + lane * 4;     // this wave's resident weight fragments
+  if constexpr (KBL > 0) {
+#pragma unroll 1
+    for (int e0 = 0; e0 < KBL * NGT; e0 += 4) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (e0 + j / 2 < KBL * NGT) v[j] = buf_load16(wrs, wlane, ((e0 + j / 2) * 2 + (j & 1)) * 1024);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (e0 + j / 2 < KBL * NGT) *(f32x4*)(wlw + ((e0 + j / 2) * 2 + (j & 1)) * 256) = v[j];
+    }
+  }
   for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
     bnl[i] = i < H ? P.out_scale[dir * H + i] : P.out_shift[dir * H + i - H];
   for (int i = threadIdx.x; i < HBUF; i += NTHREADS) hbuf[i] = 0.f;          // image of h_{-1} (buffer 0)
@@ -487,8 +504,13 @@ lstm_h2o_kernel(const LstmH2Args args) {
 #if NRV_EXP & 2
     if (exp_steady) return;
 #endif
-    bb.t[0] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2) * 1024));
-    bb.t[1] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + 1) * 1024));
+    if (KBL > 0 && e < KBL * NGT) {
+      bb.t[0] = __builtin_bit_cast(f16x8, *(const f32x4*)(wlw + (e * 2) * 256));
+      bb.t[1] = __builtin_bit_cast(f16x8, *(const f32x4*)(wlw + (e * 2 + 1) * 256));
+    } else {
+      bb.t[0] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2) * 1024));
+      bb.t[1] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + 1) * 1024));
+    }
   };
   auto loadA_in = [&](const ABase& ab, int kb, int r, AReg& d) __attribute__((always_inline)) {
 #if NRV_EXP & 4
