@@ -365,7 +365,7 @@ lstm_h2_kernel(const LstmH2Args args) {
 // into (c_s, h_s), passes the barrier and writes h_s out:
 //     in(0)                                                  prologue
 //     rec(s):   Z += h_{s-1} U          recurrent blocks, the operand split in their own shadow
-//     in(s+1):  N  = b + x_{s+1} W      input blocks; between their MFMA groups: the gate elements of
+//     in(s+1):  N  = x_{s+1} W          input blocks (the bias rides on the gate constants); between their MFMAs: the gate elements of
 //                                       Z, then the barrier, then the copy-out items of h_s
 //     Z <- N                            two accumulator sets; N is moved into Z at the end of the step
 // so that the serial section of a step is rec(s) alone.  The weight ring is kept per (k-block, gate)
