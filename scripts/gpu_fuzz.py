@@ -31,7 +31,13 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 90:
             for i in np.nonzero(arr != brr)[0]:
                 gap = p[i, brr[i]] - p[i, arr[i]]
                 assert gap <= 2e-4, (T, n, batch, prec, act, i, gap)
-    assert d <= 2e-4, (T, n, batch, prec, act, d)
+    if d > 1e-4:
+        # two f32-grade evaluations may differ by the SUM of their deviations on an ill-conditioned window:
+        # fp64 arbitrates (the engine must be within the bar, or no worse than 3x the f32 oracle's own miss)
+        r1, r2, _, _ = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float64, recurrent_act=act)
+        dh = max(float(np.abs(p1 - r1).max()), float(np.abs(p2 - r2).max()))
+        do = max(float(np.abs(q1 - r1).max()), float(np.abs(q2 - r2).max()))
+        assert dh <= max(1e-4, 3 * do), (T, n, batch, prec, act, d, dh, do)
     worst = max(worst, d); cases += 1
     rv.close()
 print(f"fuzz: {cases} cases, worst max|dp| vs f32 oracle {worst:.2e}, all argmax equal or near-tie")
