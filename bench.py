@@ -42,6 +42,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between the ranks of one node needs dmabuf IPC on this host driver (legacy IPC handles fail with
+# "hipIpcGetMemHandle: invalid argument"); must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
