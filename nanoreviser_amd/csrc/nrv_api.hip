@@ -222,6 +222,41 @@ NRV_HOST_COLD static void pack_lstm_h2(const Blob& b, int base, int K0, int s0, 
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
+// lstm_h2s_kernel (16x16x32 tiles): [dir][wave group of 16 uh units][kk 32-k blocks: input, then recurrent]
+// [gate][unit half][term][64 lanes][8 f16]; lane l: k = 32 kk + 8 (l >> 4) + j, unit = 16 (wg uh + h) + (l & 15).
+NRV_HOST_COLD static void pack_lstm_h2s(const Blob& b, int base, int K0, int s0, int K1, int s1, int H, int E,
+                                        std::vector<float>& out, std::vector<float>& bias, int uh) {
+  const int Kin = K0 + K1;
+  const int NG = H / (16 * uh), KK_IN = Kin / 32, KK = KK_IN + H / 32, epk = 4 * uh;
+  std::vector<uint16_t> w((size_t)2 * NG * KK * epk * 2 * 64 * 8, 0);
+  bias.assign((size_t)2 * NG * 4 * 16 * uh, 0.f);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);
+    const float* U = b.t(base + dir * 3 + 1);
+    const float* B = b.t(base + dir * 3 + 2);
+    for (int wg = 0; wg < NG; ++wg) {
+      for (int kk = 0; kk < KK; ++kk)
+        for (int g = 0; g < 4; ++g)
+          for (int h = 0; h < uh; ++h)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int unit = 16 * (wg * uh + h) + (lane & 15);
+                const int k = 32 * (kk < KK_IN ? kk : kk - KK_IN) + 8 * (lane >> 4) + j;
+                float v;
+                if (kk < KK_IN) v = std::ldexp(W[(size_t)k * 4 * H + g * H + unit], E - (k < K0 ? s0 : s1));
+                else v = std::ldexp(U[(size_t)k * 4 * H + g * H + unit], E - 13);
+                const size_t o = ((((((size_t)(dir * NG + wg) * KK + kk) * 4 + g) * uh + h) * 2) * 64 + lane) * 8 + j;
+                split_f16(v, &w[o], &w[o + 64 * 8]);
+              }
+      for (int g = 0; g < 4; ++g)
+        for (int c = 0; c < 16 * uh; ++c)
+          bias[((size_t)(dir * NG + wg) * 4 + g) * 16 * uh + c] = std::ldexp(B[g * H + wg * 16 * uh + c], E);
+    }
+  }
+  out.assign((w.size() + 1) / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+}
+
 // head_mlp_split_kernel: the three per-timestep dense layers as A operands of the transposed
 // product, 126 fragments [64 lanes][8 bf16] (x3 terms): lane l, element j of a fragment hold
 // W[f][n] with n = 32*mt + (l&31) and f the input feature that the B operand carries in slot
@@ -430,6 +465,7 @@ struct DevModel {
   // shift with the buffer exponents folded in, the producers' scaled epilogue constants
   size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
   size_t l_w2g[4], l_b2g[4];        // the same packed two gates per tile (lstm_h2o_kernel GPT = 2)
+  size_t l_w2s[4], l_b2s[4];        // packed for lstm_h2s_kernel (16x16x32 tiles; unit halves per wave: kUhS)
   float descale[4];
   size_t l1s2, l1h2, dsplit2, dbias2;
   size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
@@ -504,6 +540,8 @@ namespace {
       return NRV_E_HIP;                                                                  \
     }                                                                                    \
   } while (0)
+
+static const int kUhS[4] = {0, 1, 2, 1};      // unit halves per wave of lstm_h2s_kernel for lstm2..4
 
 NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
   const int T = h->T;
@@ -604,6 +642,9 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, 2);
       d.l_w2g[l] = put(wp.data(), wp.size());
       d.l_b2g[l] = put(bs.data(), bs.size());
+      pack_lstm_h2s(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, kUhS[l]);
+      d.l_w2s[l] = put(wp.data(), wp.size());
+      d.l_b2s[l] = put(bs.data(), bs.size());
       d.descale[l] = std::ldexp(1.f, -E);
       // the LDS image holds h * 2^13: scale' = scale * 2^(s_out - 13), shift' = shift * 2^s_out
       std::vector<float> one(2 * lH[l], 1.f), zero(2 * lH[l], 0.f);
@@ -828,6 +869,23 @@ static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], co
   else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
 }
 
+template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA>
+static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
+                            float* const out[2], int T, int n, int tiles) {
+  constexpr int NG = H / (16 * UH);
+  LstmH2Args sa;
+  sa.T = T; sa.n_rows = n;
+  for (int m = 0; m < 2; ++m) {
+    const DevModel& d = h->dm[m];
+    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2s[layer], d.all + d.l_b2s[layer], d.all + d.l_s2[layer],
+                                d.all + d.l_h2[layer], in0[m], in1[m], out[m], d.descale[layer]};
+  }
+  sa.n_blk = (tiles + R * WR - 1) / (R * WR);
+  dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 0, NBG, NA>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA>), grid, blk, 0, h->stream, sa);
+}
+
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
 // n + T - 1 events and the windows are formed on the device.
 static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int n, bool read_mode,
@@ -940,7 +998,9 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       const ActView i1[2] = {read_mode ? ActView{h->S[0], 16, 1, 1, 0} : win_view(h->S[0], 16),
                              read_mode ? ActView{h->S[1], 16, 1, 1, 0} : win_view(h->S[1], 16)};
       float* const o[2] = {h->X3[0], h->X3[1]};
-      launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3, 8, 4>(h, 2, i0, i1, o, T, n, tiles);
+      static const int m16b = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
+      if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles);
+      else launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3, 8, 4>(h, 2, i0, i1, o, T, n, tiles);
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
@@ -959,7 +1019,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // NRV_HT=0: one gate per accumulator tile (two pairs of waves, R = 1) instead of two (four waves, R = 2)
       static const bool ht = !(getenv("NRV_HT") && atoi(getenv("NRV_HT")) == 0);
       // 7 of its 20 weight k-blocks stay in LDS (112 KB; the layer's other LDS use is 34 KB): -1.8 %
-      if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2, 7>(h, 3, i0, none, o, T, n, tiles);
+      // NRV_MFMA16=0: the 32x32x16 tile (lstm_h2o_kernel) instead of the 16x16x32 one (lstm_h2s_kernel)
+      static const int m16 = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
+      if (m16 & 2) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2>(h, 3, i0, none, o, T, n, tiles);
+      else if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2, 7>(h, 3, i0, none, o, T, n, tiles);
       else launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
