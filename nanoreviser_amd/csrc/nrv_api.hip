@@ -869,7 +869,7 @@ static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], co
   else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA>
+template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA, int KBL = 0>
 static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
                             float* const out[2], int T, int n, int tiles) {
   constexpr int NG = H / (16 * UH);
@@ -882,8 +882,8 @@ static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], c
   }
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 0, NBG, NA>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA>), grid, blk, 0, h->stream, sa);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 0, NBG, NA, KBL>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA, KBL>), grid, blk, 0, h->stream, sa);
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -1021,7 +1021,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // 7 of its 20 weight k-blocks stay in LDS (112 KB; the layer's other LDS use is 34 KB): -1.8 %
       // NRV_MFMA16=0: the 32x32x16 tile (lstm_h2o_kernel) instead of the 16x16x32 one (lstm_h2s_kernel)
       static const int m16 = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
-      if (m16 & 2) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2>(h, 3, i0, none, o, T, n, tiles);
+      // (3 of its 10 weight k-blocks of 32 stay in LDS: 96 KB; -3 %)
+      if (m16 & 2) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3>(h, 3, i0, none, o, T, n, tiles);
       else if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2, 7>(h, 3, i0, none, o, T, n, tiles);
       else launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {

@@ -28,7 +28,9 @@ __device__ __forceinline__ f32x4 mfma16_f16(const f16x8& a, const f16x8& b, f32x
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, int UH, int ACT, int NBG, int NA>
+// KBL: the weight fragments of the first KBL input blocks stay in LDS for the whole launch (each wave its own
+// 2 EPK KBL KB, copied once in the prologue) and enter the ring by ds_read instead of from L2.
+template <int KQ0, int KQ1, int H, int R, int WR, int UH, int ACT, int NBG, int NA, int KBL = 0>
 __global__ void __launch_bounds__(64 * (H / (16 * UH)) * WR)
 lstm_h2s_kernel(const LstmH2Args args) {
   constexpr int NG = H / (16 * UH);                            // unit groups = waves per wave-row
@@ -50,6 +52,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
   __shared__ __attribute__((aligned(16))) float bnl[2 * H];
   __shared__ float cl[CLDS ? NE * NTHREADS : 1];
+  __shared__ __attribute__((aligned(16))) float wl[KBL > 0 ? NG * WR * KBL * EPK * 512 : 4];
 
 #if NRV_EXP & 64
   const unsigned long long exp_c0 = clock64(), exp_w0 = wall_clock64();    // shader clock / 100 MHz (scripts/gpu_clk.sh)
@@ -85,6 +88,19 @@ lstm_h2s_kernel(const LstmH2Args args) {
   const int hw_off = (u0 >> 2) * PLANE + (u0 & 3) + (lrow0 + 4 * kq) * 4;       // + uh 4 PLANE + (16 rt + reg) 4
   const int hp_off = (2 * kq) * PLANE + (lrow0 + l15) * 4;                      // + kkr 8 PLANE + rt 64
 
+  float* const wlw = wl + (wave * KBL * EPK) * 512 + lane * 4;     // this wave's resident weight fragments
+  if constexpr (KBL > 0) {
+#pragma unroll 1
+    for (int e0 = 0; e0 < KBL * EPK; e0 += 4) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (e0 + j / 2 < KBL * EPK) v[j] = buf_load16(wrs, wlane, ((e0 + j / 2) * 2 + (j & 1)) * 1024);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (e0 + j / 2 < KBL * EPK) *(f32x4*)(wlw + ((e0 + j / 2) * 2 + (j & 1)) * 256) = v[j];
+    }
+  }
   for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
     bnl[i] = i < H ? P.out_scale[dir * H + i] : P.out_shift[dir * H + i - H];
   for (int i = threadIdx.x; i < HBUF; i += NTHREADS) hbuf[i] = 0.f;          // image of h_{-1} (buffer 0)
@@ -126,8 +142,13 @@ lstm_h2s_kernel(const LstmH2Args args) {
   AReg a[NA][RT];
   // weight entry e = (EPK kk + 4 uh... ) in the order (kk, gate, uh) over the step's block sequence
   auto loadB = [&](int e, BReg& bb) __attribute__((always_inline)) {
-    bb.t[0] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2) * 1024));
-    bb.t[1] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + 1) * 1024));
+    if (KBL > 0 && e < KBL * EPK) {
+      bb.t[0] = __builtin_bit_cast(f16x8, *(const f32x4*)(wlw + (e * 2) * 256));
+      bb.t[1] = __builtin_bit_cast(f16x8, *(const f32x4*)(wlw + (e * 2 + 1) * 256));
+    } else {
+      bb.t[0] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2) * 1024));
+      bb.t[1] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + 1) * 1024));
+    }
   };
   auto loadA_in = [&](const ABase& ab, int kk, int rt, AReg& d) __attribute__((always_inline)) {
     const int r = rt >> 1, sub = rt & 1;
@@ -279,8 +300,13 @@ lstm_h2s_kernel(const LstmH2Args args) {
             if constexpr (WORK) {
               if (tk < TG) {
 #pragma unroll
-                for (int pc = (tk * NGP) / TG; pc < ((tk + 1) * NGP) / TG; ++pc)
+                for (int pc = (tk * NGP) / TG; pc < ((tk + 1) * NGP) / TG; ++pc) {
+#if NRV_EXP & 1024                                                  // A/B: two stages per piece, every other tick
+                  if (pc & 1) { gate_stage(gs, Z, himg_w + hw_off, pc / GST, (pc % GST) - 1); gate_stage(gs, Z, himg_w + hw_off, pc / GST, pc % GST); }
+#else
                   gate_stage(gs, Z, himg_w + hw_off, pc / GST, pc % GST);
+#endif
+                }
               } else {
 #pragma unroll
                 for (int pc = ((tk - TG) * NCP) / TC; pc < ((tk - TG + 1) * NCP) / TC; ++pc)

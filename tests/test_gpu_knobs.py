@@ -35,7 +35,7 @@ print("RESULT " + json.dumps(out))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["NRV_HT=0", "NRV_H2V=1", "NRV_CNNV=1"])
+@pytest.mark.parametrize("knob", ["NRV_HT=0", "NRV_H2V=1", "NRV_CNNV=1", "NRV_MFMA16=0"])
 def test_alternative_kernels_match_the_goldens(knob):
     name, val = knob.split("=")
     env = dict(os.environ, **{name: val})
