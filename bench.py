@@ -615,7 +615,7 @@ def run_rank(args):
             fl = flop_lstm3_launch(T, B, executed=True)
             ach = fl / avg_s / 1e12
             kname = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
-                     "f16x2": "lstm_h2o_kernel<32,16,128,2,1>"}[args.precision]
+                     "f16x2": "lstm_h2s_kernel<32,16,128,2,1,2> (16x16x32 f16 tiles)"}[args.precision]
             out["roofline"] = {
                 "kernel": f"{kname} ({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak,

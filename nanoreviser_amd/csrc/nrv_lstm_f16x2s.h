@@ -328,6 +328,10 @@ lstm_h2s_kernel(const LstmH2Args args) {
     struct SplitSt { float d0, d1; };
     SplitSt ss;
     auto split_piece = [&](Split2& o, const AReg& src, int j0, int st) __attribute__((always_inline)) {
+#if NRV_EXP & 8                                                      // timing experiment: no split at all (wrong results)
+      if (j0 == 0 && st == 0) { o.t[0] = __builtin_bit_cast(f16x8, src.v[0]); o.t[1] = __builtin_bit_cast(f16x8, src.v[1]); }
+      return;
+#endif
       const float x0 = j0 < 4 ? src.v[0][j0] : src.v[1][j0 - 4], x1 = j0 < 4 ? src.v[0][j0 + 1] : src.v[1][j0 - 3];
       if (st == 0) {
         o.t[0][j0] = (_Float16)x0;
