@@ -22,7 +22,11 @@ namespace nrv {
 // split planes at chunk 4 (2 kk + (kq >> 1)) + 2 term + (kq & 1) - the same buffers, four 256-byte runs per
 // wave instead of one KiB.  B fragments (host: pack_lstm_h2s): entry (kk, gate, uh) = [term][64 lanes][8 f16],
 // lane l: k = 32 kk + 8 (l >> 4) + j, unit 16 uh + (l & 15); an entry feeds 2R row tiles x 3 products = 6R MFMAs.
-// The recurrent operand: two float4 of the LDS image of h per (row tile, kk), split in the matrix shadow.
+// The recurrent operand is kept in LDS ALREADY SPLIT: the gate code writes h_s x 2^13 as two f16 terms into
+// the image [term][unit group of 8][row][8 f16] (a group is ROWS x 16 B + 16 B of padding), so its A fragments
+// are two 16-byte LDS reads like those of x and the recurrent phase has no VALU work at all - on this tile a
+// VALU instruction is not free (two per 16-cycle tick), and the split of 8 values per (row tile, k-block) and
+// lane was 40 % of the kernel's VALU instructions.  The copy-out adds hi + lo back before the BatchNorm.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 mfma16_f16(const f16x8& a, const f16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -38,8 +42,9 @@ lstm_h2s_kernel(const LstmH2Args args) {
   constexpr int RT = 2 * R;                                    // 16-row tiles of a wave
   constexpr int EPK = 4 * UH, TPE = 3 * RT;                    // weight entries per k-block / MFMA ticks per entry
   constexpr int ROWS = 32 * R * WR;
-  constexpr int PLANE = ROWS * 4 + 4;
-  constexpr int HBUF = (H / 4) * PLANE;
+  constexpr int GS = ROWS * 8 + 8;                             // f16 per unit group of the h image (8 of padding)
+  constexpr int TERM = (H / 8) * GS;                           // f16 per term plane
+  constexpr int HBUF = TERM;                                   // floats per image = 2 terms x TERM f16
   constexpr int NTHREADS = 64 * NG * WR;
   constexpr int LBG = NBG - 1, LA = NA - 1;
   static_assert(KQ0 % 8 == 0 && KQ1 % 8 == 0 && H % 32 == 0 && H % (16 * UH) == 0, "K must come in blocks of 32");
@@ -85,8 +90,8 @@ lstm_h2s_kernel(const LstmH2Args args) {
     bzI[uh] = bi; bzF[uh] = bf; bzO[uh] = bo;
   }
   const int u0 = hg * 16 * UH + l15;                           // this lane's unit of half 0 (half uh: + 16 uh)
-  const int hw_off = (u0 >> 2) * PLANE + (u0 & 3) + (lrow0 + 4 * kq) * 4;       // + uh 4 PLANE + (16 rt + reg) 4
-  const int hp_off = (2 * kq) * PLANE + (lrow0 + l15) * 4;                      // + kkr 8 PLANE + rt 64
+  const int hw_off = (u0 >> 3) * GS + (lrow0 + 4 * kq) * 8 + (u0 & 7);          // f16; + uh 2 GS + (16 rt + reg) 8; lo: + TERM
+  const int hp_off = kq * GS + (lrow0 + l15) * 8;                               // f16; + kkr 4 GS + rt 128; lo: + TERM
 
   float* const wlw = wl + (wave * KBL * EPK) * 512 + lane * 4;     // this wave's resident weight fragments
   if constexpr (KBL > 0) {
@@ -161,10 +166,10 @@ lstm_h2s_kernel(const LstmH2Args args) {
       d.v[0] = buf_load16(ab.r1[r], ab.v1[r][sub], (kk - KK0) * 4096);
     }
   };
-  auto loadA_rec = [&](const float* hp, int kkr, int rt, AReg& d) __attribute__((always_inline)) {
-    const float* qh = hp + kkr * 8 * PLANE + rt * 64;
+  auto loadA_rec = [&](const _Float16* hp, int kkr, int rt, AReg& d) __attribute__((always_inline)) {
+    const _Float16* qh = hp + kkr * 4 * GS + rt * 128;
+    d.v[1] = *(const f32x4*)(qh + TERM);                 // lo first, as for x
     d.v[0] = *(const f32x4*)(qh);
-    d.v[1] = *(const f32x4*)(qh + PLANE);
   };
   // hi*lo, lo*hi, hi*hi: the first product of an entry takes the LAST-requested fragment of both operands
   constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
@@ -173,9 +178,9 @@ lstm_h2s_kernel(const LstmH2Args args) {
   // a tick is 16 cycles of which the MFMA holds the issue port for 8: at most two VALU instructions ride along
   // for free, so a gate element is cut into TWELVE stages here (a heavier piece delays its MFMA and the pipe
   // does not get the time back on the next, lighter tick)
-  constexpr int GST = 12;
-  struct GateSt { float zi, zf, zg, zo, cp, p, hv, t; };
-  auto gate_stage = [&](GateSt& g, const f32x4 (&Z)[4][UH][RT], float* hw, int e, int st) __attribute__((always_inline)) {
+  constexpr int GST = 14;
+  struct GateSt { float zi, zf, zg, zo, cp, p, hv, t; _Float16 hh, hl; };
+  auto gate_stage = [&](GateSt& g, const f32x4 (&Z)[4][UH][RT], _Float16* hw, int e, int st) __attribute__((always_inline)) {
     const int uh = e / (RT * 4), rt = (e / 4) % RT, reg = e % 4;
     if (st == 0) {
       g.zi = Z[0][uh][rt][reg]; g.zf = Z[1][uh][rt][reg];
@@ -213,35 +218,39 @@ lstm_h2s_kernel(const LstmH2Args args) {
     } else if (st == 10) {
       // og * tanh(c) * 2^13, the scale riding on tanh's last fma
       g.hv = g.zo * __builtin_fmaf(g.t, -2.0f * kHScale, kHScale);
+    } else if (st == 11) {
+      g.hh = (_Float16)g.hv;
+    } else if (st == 12) {
+      g.hl = (_Float16)(g.hv - (float)g.hh);
     } else {
-      hw[uh * 4 * PLANE + (rt * 16 + reg) * 4] = g.hv;
+      hw[uh * 2 * GS + (rt * 16 + reg) * 8] = g.hh;
+      hw[uh * 2 * GS + (rt * 16 + reg) * 8 + TERM] = g.hl;
     }
   };
   constexpr int ITEMS = (H / 16) * 2 * ROWS;
   constexpr int NIT = ITEMS / NTHREADS;
   static_assert(ITEMS % NTHREADS == 0, "copy-out items must divide evenly");
-  constexpr int CST = 8;                                       // stages of one copy-out item
-  struct CopySt { f32x4 x0, x1; Split2 o; float* dst; };
-  auto copy_stage = [&](CopySt& k, const float* himg, int t, int i, int st) __attribute__((always_inline)) {
+  constexpr int CST = 12;                                      // stages of one copy-out item
+  struct CopySt { f16x8 hi, lo; f32x4 x0, x1; Split2 o; float* dst; };
+  auto copy_stage = [&](CopySt& k, const _Float16* himg, int t, int i, int st) __attribute__((always_inline)) {
     const int it = threadIdx.x + i * NTHREADS;
     constexpr int KBH = H / 16;
-    const int kbh = it / ROWS, rr = it % ROWS;          // kbh = 2*kbo + hf: features 8*kbh .. 8*kbh + 7
-    const int kq2 = 2 * kbh;
+    const int kbh = it / ROWS, rr = it % ROWS;          // kbh = 2*kbo + hf: features 8*kbh .. 8*kbh + 7 = unit group kbh
     if (st == 0) {
-      k.x0 = *(const f32x4*)(himg + kq2 * PLANE + rr * 4);
-      k.x1 = *(const f32x4*)(himg + (kq2 + 1) * PLANE + rr * 4);
+      k.hi = *(const f16x8*)(himg + kbh * GS + rr * 8);
+      k.lo = *(const f16x8*)(himg + kbh * GS + rr * 8 + TERM);
       const int tile = blk.rowblk * (R * WR) + rr / 32;
       k.dst = P.out + ((size_t)(tile * T + t) * (2 * H / 4) + (dir * KBH + (kbh >> 1)) * 4 + (kbh & 1)) * 128 + (rr & 31) * 4;
-    } else if (st == 1) {
-      const f32x4 s0 = *(const f32x4*)(bnl + kq2 * 4), h0 = *(const f32x4*)(bnl + H + kq2 * 4);
+    } else if (st < 5) {                                // BatchNorm of hi + lo, two features per stage
+      const int j0 = 2 * (st - 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) k.x0[q] = k.x0[q] * s0[q] + h0[q];
-    } else if (st == 2) {
-      const f32x4 s1 = *(const f32x4*)(bnl + kq2 * 4 + 4), h1 = *(const f32x4*)(bnl + H + kq2 * 4 + 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) k.x1[q] = k.x1[q] * s1[q] + h1[q];
-    } else if (st < 7) {                                // the split, two elements per stage
-      const int j0 = 2 * (st - 3);
+      for (int j = j0; j < j0 + 2; ++j) {
+        const float sc = bnl[kbh * 8 + j], sh = bnl[H + kbh * 8 + j];
+        const float v = __builtin_fmaf((float)k.hi[j], sc, __builtin_fmaf((float)k.lo[j], sc, sh));
+        if (j < 4) k.x0[j] = v; else k.x1[j - 4] = v;
+      }
+    } else if (st < 9) {                                // the split, two elements per stage
+      const int j0 = 2 * (st - 5);
 #pragma unroll
       for (int j = j0; j < j0 + 2; ++j) {
         const float x = j < 4 ? k.x0[j] : k.x1[j - 4];
@@ -249,8 +258,9 @@ lstm_h2s_kernel(const LstmH2Args args) {
         k.o.t[0][j] = hh;
         k.o.t[1][j] = (_Float16)(x - (float)hh);
       }
-    } else {
+    } else if (st == 9) {
       *(f16x8*)k.dst = k.o.t[0];
+    } else if (st == 10) {
       *(f16x8*)(k.dst + 2 * 128) = k.o.t[1];
     }
   };
@@ -265,7 +275,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
   constexpr int TC = NTICK - TG;
   static_assert(TG >= 1 && TC >= 1, "no room for the gates / copy-out in the input phase");
   auto in_phase = [&](auto work_tag, f32x4 (&N)[4][UH][RT], const f32x4 (&Z)[4][UH][RT], const ABase& xb,
-                      const float* hp_next, float* himg_w, int t_out, const ABase& xb_wrap) __attribute__((always_inline)) {
+                      const _Float16* hp_next, _Float16* himg_w, int t_out, const ABase& xb_wrap) __attribute__((always_inline)) {
     constexpr bool WORK = decltype(work_tag)::value;
     GateSt gs;
     CopySt cs;
@@ -320,37 +330,8 @@ lstm_h2s_kernel(const LstmH2Args args) {
       }
     }
   };
-  // ---- rec(): Z += h U over the recurrent blocks; the split of the next block's units runs in the shadow of
-  // this block's MFMAs (two values of one row tile per piece, three stages each).
-  auto rec_phase = [&](f32x4 (&Z)[4][UH][RT], const float* hp, const ABase& xb_next) __attribute__((always_inline)) {
-    Split2 sp[2][RT];
-    constexpr int NSP = 3 * 4 * RT, NTK = EPK * TPE;           // stage pieces / MFMA ticks per k-block
-    struct SplitSt { float d0, d1; };
-    SplitSt ss;
-    auto split_piece = [&](Split2& o, const AReg& src, int j0, int st) __attribute__((always_inline)) {
-#if NRV_EXP & 8                                                      // timing experiment: no split at all (wrong results)
-      if (j0 == 0 && st == 0) { o.t[0] = __builtin_bit_cast(f16x8, src.v[0]); o.t[1] = __builtin_bit_cast(f16x8, src.v[1]); }
-      return;
-#endif
-      const float x0 = j0 < 4 ? src.v[0][j0] : src.v[1][j0 - 4], x1 = j0 < 4 ? src.v[0][j0 + 1] : src.v[1][j0 - 3];
-      if (st == 0) {
-        o.t[0][j0] = (_Float16)x0;
-        o.t[0][j0 + 1] = (_Float16)x1;
-      } else if (st == 1) {
-        ss.d0 = x0 - (float)o.t[0][j0];
-        ss.d1 = x1 - (float)o.t[0][j0 + 1];
-      } else {
-        o.t[1][j0] = (_Float16)ss.d0;
-        o.t[1][j0 + 1] = (_Float16)ss.d1;
-      }
-    };
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j0 = 0; j0 < 8; j0 += 2)
-#pragma unroll
-        for (int st = 0; st < 3; ++st) split_piece(sp[0][rt], a[KK_IN % NA][rt], j0, st);
-    __builtin_amdgcn_sched_barrier(0);
+  // ---- rec(): Z += h U over the recurrent blocks: MFMAs and requests only (the operand arrives split).
+  auto rec_phase = [&](f32x4 (&Z)[4][UH][RT], const _Float16* hp, const ABase& xb_next) __attribute__((always_inline)) {
 #pragma unroll
     for (int kr = 0; kr < KK_REC; ++kr) {
       const int kk = KK_IN + kr;
@@ -370,22 +351,15 @@ lstm_h2s_kernel(const LstmH2Args args) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int pr = 0; pr < 3; ++pr) {
-            const int tk = (ge * RT + rt) * 3 + pr;
-            Z[g][uh][rt] = mfma16_f16(sp[kr & 1][rt].t[PA[pr]], b[e % NBG].t[PB[pr]], Z[g][uh][rt]);
-            if (kr + 1 < KK_REC) {
-#pragma unroll
-              for (int pc = (tk * NSP) / NTK; pc < ((tk + 1) * NSP) / NTK; ++pc)
-                split_piece(sp[(kr + 1) & 1][pc / 12], a[(kk + 1) % NA][pc / 12], 2 * ((pc / 3) % 4), pc % 3);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          for (int pr = 0; pr < 3; ++pr)
+            Z[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]], Z[g][uh][rt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
 
   f32x4 Z[4][UH][RT], N[4][UH][RT];
-  auto himg = [&](int s) __attribute__((always_inline)) { return hbuf + ((s + 1) & 1) * HBUF; };   // image of h_s
+  auto himg = [&](int s) __attribute__((always_inline)) { return (_Float16*)(hbuf + ((s + 1) & 1) * HBUF); };   // image of h_s
   auto t_of = [&](int s) __attribute__((always_inline)) { return dir ? (T - 1 - s) : s; };
 
   // prologue: the rings' first entries, then in(0) straight into Z
