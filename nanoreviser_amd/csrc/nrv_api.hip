@@ -466,6 +466,8 @@ struct DevModel {
   size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
   size_t l_w2g[4], l_b2g[4];        // the same packed two gates per tile (lstm_h2o_kernel GPT = 2)
   size_t l_w2s[4], l_b2s[4];        // packed for lstm_h2s_kernel (16x16x32 tiles; unit halves per wave: kUhS)
+  size_t l_w2sf = 0, l_b2sf = 0;    // 256->64 layer with the BatchNorm in front of it folded into weights and bias
+  float descale_f = 1.f;            // (its input is then the raw h x 2^13 of the 192->128 layer)
   float descale[4];
   size_t l1s2, l1h2, dsplit2, dbias2;
   size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
@@ -645,6 +647,29 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       pack_lstm_h2s(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, kUhS[l]);
       d.l_w2s[l] = put(wp.data(), wp.size());
       d.l_b2s[l] = put(bs.data(), bs.size());
+      if (l == 3) {
+        // BatchNorm(256) between the 192->128 and the 256->64 layer, folded into the latter:
+        //   (h sc + sh) W + b = h (diag(sc) W) + (b + sh W),  so that the former's output is h x 2^13 as it lies in LDS
+        std::vector<float> all(b.p, b.p + b.off.back() + (size_t)C);          // the blob ends with final_out's bias [C]
+        for (int dir = 0; dir < 2; ++dir) {
+          float* W = all.data() + b.off[lbase[3] + dir * 3 + 0];
+          float* B = all.data() + b.off[lbase[3] + dir * 3 + 2];
+          const int N4 = 4 * lH[3];
+          for (int c = 0; c < N4; ++c) {
+            double acc = B[c];
+            for (int k = 0; k < 256; ++k) acc += (double)sh3[k] * (double)W[(size_t)k * N4 + c];
+            B[c] = (float)acc;
+          }
+          for (int k = 0; k < 256; ++k)
+            for (int c = 0; c < N4; ++c) W[(size_t)k * N4 + c] *= sc3[k];
+        }
+        const Blob bf{all.data(), b.off};
+        const int Ef = plan_exponent(bf, lbase[3], 256, 13, 0, 0, lH[3]);
+        pack_lstm_h2s(bf, lbase[3], 256, 13, 0, 0, lH[3], Ef, wp, bs, kUhS[3]);
+        d.l_w2sf = put(wp.data(), wp.size());
+        d.l_b2sf = put(bs.data(), bs.size());
+        d.descale_f = std::ldexp(1.f, -Ef);
+      }
       d.descale[l] = std::ldexp(1.f, -E);
       // the LDS image holds h * 2^13: scale' = scale * 2^(s_out - 13), shift' = shift * 2^s_out
       std::vector<float> one(2 * lH[l], 1.f), zero(2 * lH[l], 0.f);
@@ -869,21 +894,22 @@ static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], co
   else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA, int KBL = 0>
+template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA, int KBL = 0, bool RAW = false>
 static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
-                            float* const out[2], int T, int n, int tiles) {
+                            float* const out[2], int T, int n, int tiles, bool folded_in = false) {
   constexpr int NG = H / (16 * UH);
   LstmH2Args sa;
   sa.T = T; sa.n_rows = n;
   for (int m = 0; m < 2; ++m) {
     const DevModel& d = h->dm[m];
-    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2s[layer], d.all + d.l_b2s[layer], d.all + d.l_s2[layer],
-                                d.all + d.l_h2[layer], in0[m], in1[m], out[m], d.descale[layer]};
+    sa.m[m] = LstmH2ModelParams{d.all + (folded_in ? d.l_w2sf : d.l_w2s[layer]), d.all + (folded_in ? d.l_b2sf : d.l_b2s[layer]),
+                                d.all + d.l_s2[layer], d.all + d.l_h2[layer], in0[m], in1[m], out[m],
+                                folded_in ? d.descale_f : d.descale[layer]};
   }
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 0, NBG, NA, KBL>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA, KBL>), grid, blk, 0, h->stream, sa);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 0, NBG, NA, KBL, RAW>), grid, blk, 0, h->stream, sa);
+  else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA, KBL, RAW>), grid, blk, 0, h->stream, sa);
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -999,7 +1025,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                              read_mode ? ActView{h->S[1], 16, 1, 1, 0} : win_view(h->S[1], 16)};
       float* const o[2] = {h->X3[0], h->X3[1]};
       static const int m16b = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
-      if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles);
+      // both big layers on lstm_h2s_kernel: this one hands over h x 2^13 as it lies in LDS and the BatchNorm
+      // behind it lives in the next layer's weights
+      if (m16b == 3) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 0, true>(h, 2, i0, i1, o, T, n, tiles);
+      else if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles);
       else launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3, 8, 4>(h, 2, i0, i1, o, T, n, tiles);
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
@@ -1022,7 +1051,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // NRV_MFMA16=0: the 32x32x16 tile (lstm_h2o_kernel) instead of the 16x16x32 one (lstm_h2s_kernel)
       static const int m16 = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
       // (3 of its 10 weight k-blocks of 32 stay in LDS: 96 KB; -3 %)
-      if (m16 & 2) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3>(h, 3, i0, none, o, T, n, tiles);
+      if (m16 & 2) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles, m16 == 3);   // no BatchNorm behind this layer
       else if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 3, 3, 8, 4, 2, 7>(h, 3, i0, none, o, T, n, tiles);
       else launch_lstm_h2<64, 0, 64, 1, 2, false, 3, 3, 16, 4>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {

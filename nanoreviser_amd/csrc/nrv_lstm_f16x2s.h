@@ -34,7 +34,9 @@ __device__ __forceinline__ f32x4 mfma16_f16(const f16x8& a, const f16x8& b, f32x
 
 // KBL: the weight fragments of the first KBL input blocks stay in LDS for the whole launch (each wave its own
 // 2 EPK KBL KB, copied once in the prologue) and enter the ring by ds_read instead of from L2.
-template <int KQ0, int KQ1, int H, int R, int WR, int UH, int ACT, int NBG, int NA, int KBL = 0>
+// RAW: the layer's output is h x 2^13 itself (no BatchNorm behind it, or one that the host folded into the next
+// layer's weights): the copy-out moves the two term planes of the image to memory as they are, no arithmetic.
+template <int KQ0, int KQ1, int H, int R, int WR, int UH, int ACT, int NBG, int NA, int KBL = 0, bool RAW = false>
 __global__ void __launch_bounds__(64 * (H / (16 * UH)) * WR)
 lstm_h2s_kernel(const LstmH2Args args) {
   constexpr int NG = H / (16 * UH);                            // unit groups = waves per wave-row
@@ -230,7 +232,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
   constexpr int ITEMS = (H / 16) * 2 * ROWS;
   constexpr int NIT = ITEMS / NTHREADS;
   static_assert(ITEMS % NTHREADS == 0, "copy-out items must divide evenly");
-  constexpr int CST = 12;                                      // stages of one copy-out item
+  constexpr int CST = RAW ? 4 : 12;                            // stages of one copy-out item
   struct CopySt { f16x8 hi, lo; f32x4 x0, x1; Split2 o; float* dst; };
   auto copy_stage = [&](CopySt& k, const _Float16* himg, int t, int i, int st) __attribute__((always_inline)) {
     const int it = threadIdx.x + i * NTHREADS;
@@ -241,6 +243,9 @@ lstm_h2s_kernel(const LstmH2Args args) {
       k.lo = *(const f16x8*)(himg + kbh * GS + rr * 8 + TERM);
       const int tile = blk.rowblk * (R * WR) + rr / 32;
       k.dst = P.out + ((size_t)(tile * T + t) * (2 * H / 4) + (dir * KBH + (kbh >> 1)) * 4 + (kbh & 1)) * 128 + (rr & 31) * 4;
+    } else if (RAW) {
+      if (st == 1) *(f16x8*)k.dst = k.hi;
+      else if (st == 2) *(f16x8*)(k.dst + 2 * 128) = k.lo;
     } else if (st < 5) {                                // BatchNorm of hi + lo, two features per stage
       const int j0 = 2 * (st - 1);
 #pragma unroll
