@@ -35,10 +35,9 @@ print("RESULT " + json.dumps(out))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["NRV_HT=0", "NRV_H2V=1", "NRV_CNNV=1", "NRV_MFMA16=0"])
+@pytest.mark.parametrize("knob", ["NRV_MFMA16=0", "NRV_MFMA16=0,NRV_HT=0", "NRV_MFMA16=1", "NRV_MFMA16=2", "NRV_H2V=1", "NRV_CNNV=1"])
 def test_alternative_kernels_match_the_goldens(knob):
-    name, val = knob.split("=")
-    env = dict(os.environ, **{name: val})
+    env = dict(os.environ, **dict(kv.split("=") for kv in knob.split(",")))
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
