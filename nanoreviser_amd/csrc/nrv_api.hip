@@ -1027,7 +1027,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       static const int m16b = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
       // both big layers on lstm_h2s_kernel: this one hands over h x 2^13 as it lies in LDS and the BatchNorm
       // behind it lives in the next layer's weights
-      if (m16b == 3) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 0, true>(h, 2, i0, i1, o, T, n, tiles);
+      // (cell state in registers; 1 of its 10 weight k-blocks of 32 resident in LDS: 64 KB)
+      if (m16b == 3) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles);
       else if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles);
       else launch_lstm_h2<32, 16, 128, 2, 1, false, 3, 3, 8, 4>(h, 2, i0, i1, o, T, n, tiles);
     } else if (h->split & 4) {

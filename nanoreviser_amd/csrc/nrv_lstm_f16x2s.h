@@ -55,7 +55,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
   static_assert(LA >= 1 && LA <= KK_IN && LA <= KK_REC && LBG <= EPK * KK_REC, "leads must stay inside a phase");
 
   constexpr int NE = UH * RT * 4;                              // gate elements per lane
-  constexpr bool CLDS = NE > 16;                               // cell state in LDS when the registers are needed elsewhere
+  constexpr bool CLDS = NE > 32;                               // cell state in LDS when the registers are needed elsewhere (not since h is kept split: no split buffers)
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
   __shared__ __attribute__((aligned(16))) float bnl[2 * H];
   __shared__ float cl[CLDS ? NE * NTHREADS : 1];
