@@ -116,7 +116,7 @@ int nrv_get_batch(nrv_handle* h);
  *   NRV_PREC_F16X2 (default)  every operand is scaled by a power of two fixed at nrv_create from static
  *                    bounds, split into two f16 terms, and each product formed from three term pairs
  *                    on the f16 matrix pipe; activations travel between the kernels already split.
- *                    ~2.3x the f32 mode's throughput.
+ *                    ~2.6x the f32 mode's throughput.
  *   NRV_PREC_BF16X3  every f32 operand is split exactly into three bf16 terms and each product formed
  *                    from the six term pairs that matter, on the bf16 matrix pipe; ~1.5x f32 mode;
  *   NRV_PREC_F32     plain f32 matrix instructions.

@@ -17,7 +17,8 @@
 //     Weights are pre-packed on the host into the matching B-fragment order (f32 and split-bf16
 //     forms), so B operands stream L2 -> VGPR with no LDS staging.
 //   * Six launches per group of windows in the default mode: cnn_h2_kernel (signal branch),
-//     lstm1_kernel, three lstm_h2o_kernel Bi-LSTM layers, head_h2_kernel (seven in the other modes:
+//     lstm1_kernel, lstm_h2o_kernel (32->64) and two lstm_h2s_kernel (192->128, 256->64: 16x16x32
+//     tiles) Bi-LSTM layers, head_h2_kernel (seven in the other modes:
 //     cnn_kernel, lstm1_kernel, lstm_pair_kernel / lstm_split_kernel or lstm_layer_kernel,
 //     head_mlp(_split)_kernel, head_final_kernel); plus segment_kernel when reads arrive as raw
 //     samples.  Rows (windows) are independent: no inter-workgroup communication anywhere.
