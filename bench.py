@@ -16,16 +16,22 @@ non-zero exit code.
 
 Inputs are resident in HBM before the timed region.  Reads/windows are independent, so ranks own
 disjoint shards and the data path has NO collective (weak scaling); the only communication is the
-barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+barrier and three scalar reductions of the control plane, on `gloo` with CPU tensors - no RCCL anywhere
+(a workload without collectives must not depend on RCCL initialising).  Rank 0 prints ONE JSON line.
+`--share-device` maps rank r to device r % device_count, so that a 1-GPU box can rehearse the N-rank
+path with the real engine (tests/test_gpu_multirank.py); it is reported in `config` and never the default.
 
 Besides the contract keys the line carries (N = 1, rank 0; --no-extras turns them off):
   roofline            dominant kernel (lstm3), hipEvent pairs on the launch stream INSIDE the timed
                       region on every 8th launch (a bracket costs ~12 us of idle pipe, so bracketing
                       every launch would perturb a 20-step run by 2 %)
   kernel_us           every kernel, from a separate untimed pass after the timed region
-  f32_mode            the same step with plain f32 matrix instructions (roofline 157.3 TFLOP/s)
+  roofline_f32        the same step with plain f32 matrix instructions (IEEE f32, the reference's own
+                      precision; ceiling 157.3 TFLOP/s), measured with the SAME protocol as `value`:
+                      priming, warm-up, K timed steps, every-8th bracket, untimed all-kernel pass
   host_inclusive      nrv_predict / nrv_predict_read / nrv_predict_reads_raw from HOST memory
-                      (H2D + D2H inside the timed call) - never `value`
+                      (H2D + D2H inside the timed call) - never `value`; cli_e2e: the command line itself,
+                      fast5 files in, FASTA files out, in a child process (NanoReviser.py:105-183)
   read_mode           config C5: one 200 k-event read, human weights, device-formed windows
   configs             C2 (ecoli, batch 512) and C3 (human, batch 4096) on the replicated fixture reads
   cpu_baseline        oracle/nrv_oracle.c (plain-C f32 port of the reference graph - test
@@ -42,10 +48,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# RCCL between the ranks of one node needs dmabuf IPC on this host driver (legacy IPC handles fail with
-# "hipIpcGetMemHandle: invalid argument"); must be in the environment before the HIP runtime starts
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32 matrix)
@@ -93,24 +95,26 @@ def mode_peak(precision):
 # ranks
 # ------------------------------------------------------------------------------------------------
 class Dist:
-    """One process per GPU; RCCL ('nccl') on GPUs, gloo for the CPU dry run."""
+    """One process per GPU.  The control plane (one barrier pair, three scalar reductions) runs on gloo with
+    CPU tensors in every configuration: the data path has no collective, so nothing here touches RCCL."""
 
-    def __init__(self, backend):
+    def __init__(self, backend="gloo"):
         import torch.distributed as dist
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = dist if self.world > 1 else None
-        self.backend = backend
+        self.backend = "gloo"
         if self.dist is not None and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
 
-    def _tensor(self, v, dtype):
+    def _reduce(self, v, dtype, op):
         import torch
-        dev = f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu"
-        return torch.tensor([v], dtype=dtype, device=dev)
+        t = torch.tensor([v], dtype=dtype)
+        self.dist.all_reduce(t, op=op)
+        return t.item()
 
     def barrier(self):
         if self.dist is not None:
@@ -118,19 +122,15 @@ class Dist:
 
     def max_float(self, v):
         import torch
-        if self.dist is None:
-            return float(v)
-        t = self._tensor(v, torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(v) if self.dist is None else float(self._reduce(v, torch.float64, self.dist.ReduceOp.MAX))
+
+    def min_float(self, v):
+        import torch
+        return float(v) if self.dist is None else float(self._reduce(v, torch.float64, self.dist.ReduceOp.MIN))
 
     def sum_int(self, v):
         import torch
-        if self.dist is None:
-            return int(v)
-        t = self._tensor(v, torch.int64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return int(t.item())
+        return int(v) if self.dist is None else int(self._reduce(v, torch.int64, self.dist.ReduceOp.SUM))
 
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
@@ -365,7 +365,7 @@ def fixture_reads():
     return out
 
 
-def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step):
+def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_helper=None):
     from nanoreviser_amd.engine import Reviser
     from nanoreviser_amd.weights import load_species
     from nanoreviser_amd import workload as W
@@ -379,26 +379,16 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step):
         return (torch.empty(n, 6, device=dev), torch.empty(n, 5, device=dev),
                 torch.empty(n, dtype=torch.int8, device=dev), torch.empty(n, dtype=torch.int8, device=dev))
 
-    # ---- f32 mode: the same step on plain f32 matrix instructions
+    # ---- f32 mode (IEEE f32 matrix instructions: the reference's own precision) - same protocol as `value`
     rv = Reviser(m1, m2, device=local_rank, batch=B, precision="f32")
     rv.set_stream(torch.cuda.current_stream().cuda_stream)
     d_sig, d_rd = torch.from_numpy(sig).to(dev), torch.from_numpy(rd).to(dev)
     o = outputs(B)
     ptrs = (d_sig.data_ptr(), d_rd.data_ptr(), B) + tuple(x.data_ptr() for x in o)
-    ms = _time_calls(lambda: rv.predict_device(*ptrs), sync, max(10, min(args.steps, 50)), warm=10) * 1e3
-    rv.prof_enable(2)
-    rv.prof_read()
-    for _ in range(16):
-        rv.predict_device(*ptrs)
-    sync()
-    pr = rv.prof_read()
-    k3 = list(pr.keys())[3]
-    us3 = pr[k3][0] / max(pr[k3][1], 1) * 1e3
-    whole = flop_per_window(T) * B / (ms * 1e-3) / 1e12
-    out["f32_mode"] = {"ms_per_step": ms, "bases_per_s": B / (ms * 1e-3),
-                       "whole_step_tflops": whole, "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
-                       "lstm3_us": us3,
-                       "lstm3_frac_of_f32_mfma_peak": flop_lstm3_launch(T, B) / (us3 * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    m = measure(rv, lambda: rv.predict_device(*ptrs), sync, Dist(), args, prime=max(args.prime // 3, 20), rank0=True)
+    out.update(roofline_blocks(args, T, B, "f32", m, suffix="_f32"))
+    out["roofline_f32"].update({"ms_per_step": m["ms_per_step"], "bases_per_s": B / (m["ms_per_step"] * 1e-3),
+                                "steps": args.steps, "warmup": args.warmup, "prime": max(args.prime // 3, 20)})
     rv.close()
     del d_sig, d_rd
 
@@ -413,6 +403,8 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step):
     del hsig, hrd
     out["host_inclusive"] = hi
     rv.close()
+    if cli_helper is not None:                               # the command line itself, in a process of its own
+        hi["cli_e2e"] = cli_helper.run()
 
     # ---- C5: one long read, human weights, streamed in device-formed window groups
     h1, h2 = load_species("human")
@@ -475,6 +467,161 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step):
 
 
 # ------------------------------------------------------------------------------------------------
+# the measurement protocol (used for `value` and for roofline_f32)
+# ------------------------------------------------------------------------------------------------
+def measure(rv, step, sync, d, args, prime, rank0):
+    """Untimed priming (the first unsynchronised bursts of launches of a process pay one-off costs, ~35 ms
+    inside the first ~1000 launches, and the chip needs ~0.2 s of load to settle on the clock it sustains),
+    W warm-up steps, then EXACTLY K steps between barrier + device sync; the dominant kernel is bracketed by
+    hipEvents on every 8th launch INSIDE the timed region; every kernel in an untimed pass behind it."""
+    for _ in range(prime):
+        step()
+    sync()
+    prof_mode = 0
+    if not args.no_prof:
+        prof_mode = 1 if args.prof_all else 3            # 3: the dominant kernel, every 8th launch
+        rv.prof_enable(prof_mode)
+        rv.prof_read()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if prof_mode:
+        rv.prof_enable(prof_mode)                        # restart the every-8th tick; drops warm-up samples
+        rv.prof_read()
+    elapsed, mine = timed_steps(d, step, sync, args.steps, 0)
+    prof = rv.prof_read() if prof_mode else {}
+    kernel_us = {}
+    if prof_mode and rank0:
+        rv.prof_enable(1)
+        rv.prof_read()
+        for _ in range(max(8, min(args.steps, 32))):
+            step()
+        sync()
+        kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in rv.prof_read().items() if c > 0}
+    rv.prof_enable(0)
+    return {"elapsed": elapsed, "mine": mine, "ms_per_step": elapsed / args.steps * 1e3, "prof": prof,
+            "kernel_us": kernel_us, "prof_mode": prof_mode}
+
+
+KERNEL_NAME = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
+               "f16x2": "lstm_h2s_kernel<32,16,128,2,1,2> (16x16x32 f16 tiles)"}
+
+
+def roofline_blocks(args, T, B, precision, m, suffix=""):
+    """roofline / roofline_whole_step / kernel_us of one measure() result."""
+    prof, kernel_us = m["prof"], m["kernel_us"]
+    out = {}
+    if not prof:
+        return out
+    peak, peak_note = mode_peak(precision)
+    names = list(prof.keys())
+    k3 = names[3]
+    if prof[k3][1] > 0:
+        avg_s = prof[k3][0] / prof[k3][1] * 1e-3
+        where = "hipEvent pairs on the launch stream inside the timed region" + \
+            (", every 8th launch bracketed" if m["prof_mode"] == 3 else "")
+        n_l = prof[k3][1]
+    else:                                             # fewer than one sampled launch: use the untimed pass
+        avg_s = kernel_us[k3] * 1e-6
+        where, n_l = "hipEvent pairs on the launch stream, untimed pass right after the timed region", 0
+    fl = flop_lstm3_launch(T, B, executed=True)
+    ach = fl / avg_s / 1e12
+    out["roofline" + suffix] = {
+        "kernel": f"{KERNEL_NAME[precision]} ({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
+        "unit": "TFLOP/s", "frac": ach / peak,
+        "traffic": load_traffic(T, B, precision),
+        "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": n_l,
+        "avg_launch_us_untimed_pass": kernel_us.get(k3),
+        "timing": where, "peak_note": peak_note,
+        "executed_tflops": ach * PRODUCTS[precision],
+        "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+    }
+    whole = flop_per_window(T) * B / (m["ms_per_step"] * 1e-3) / 1e12
+    out["roofline_whole_step" + suffix] = {"achieved": whole, "peak": peak, "unit": "TFLOP/s", "frac": whole / peak,
+                                           "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
+                                           "flop_per_window": flop_per_window(T)}
+    out["kernel_us" + suffix] = kernel_us
+    out["kernel_us_sum" + suffix] = sum(kernel_us.values())
+    return out
+
+
+class CliHelper:
+    """End-to-end figure of the command line (fast5 in, FASTA out: NanoReviser.py:105-183) for the JSON line.
+    The CLI must run in a process of its own, and a process that has initialised the GPU must not exec
+    another program: so a helper child (`bench.py --cli-e2e-helper`, which never touches a GPU itself) is
+    started BEFORE this process makes its first HIP call, waits on its stdin, and on "go" runs
+    `python NanoReviser.py` on the two committed fixture reads x REP as ITS child, timing it from outside."""
+
+    def __init__(self, reps, threads):
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cli-e2e-helper",
+                                   "--cli-reps", str(reps), "--cli-threads", str(threads)],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+    def run(self):
+        try:
+            out, _ = self.p.communicate("go\n", timeout=600)
+            return json.loads(out.strip().splitlines()[-1])
+        except Exception as e:
+            self.close()
+            return {"error": repr(e)}
+
+    def close(self):
+        if self.p.poll() is None:
+            try:
+                self.p.communicate("quit\n", timeout=10)
+            except Exception:
+                self.p.kill()
+
+
+def cli_e2e_helper(reps, threads):
+    """Body of the helper child (no GPU call in this process, ever)."""
+    import glob
+    import shutil
+    import tempfile
+    if sys.stdin.readline().strip() != "go":
+        return 0
+    src = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fast5", "*.fast5")))
+    work = tempfile.mkdtemp(prefix="nrv_cli_e2e_")
+    try:
+        din, dout = os.path.join(work, "in"), os.path.join(work, "out") + "/"
+        os.makedirs(din)
+        for i, f in enumerate(src):
+            for k in range(reps):
+                os.symlink(f, os.path.join(din, f"r{i}_{k}.fast5"))
+        res = {"reads": len(src) * reps, "threads": threads}
+        for name, n in (("start_up", 2), ("run", None)):     # two reads first: what a run costs before it streams
+            if n is not None:
+                d2 = os.path.join(work, "in2")
+                os.makedirs(d2, exist_ok=True)
+                for f in sorted(os.listdir(din))[:n]:
+                    if not os.path.exists(os.path.join(d2, f)):
+                        os.symlink(os.path.realpath(os.path.join(din, f)), os.path.join(d2, f))
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "NanoReviser.py"), "-d", din if n is None else d2,
+                                "-o", dout, "-S", "ecoli", "--thread", str(threads), "--gpus", "1"],
+                               capture_output=True, text=True, timeout=500)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                res["error"] = f"{name}: rc {r.returncode}: {r.stderr[-300:]}"
+                break
+            line = [ln for ln in r.stdout.splitlines() if "bases/s end to end" in ln]
+            if name == "start_up":
+                res["start_up_s_two_reads"] = dt
+            else:
+                nb = int(line[-1].split(" reads, ")[1].split(" bases")[0]) if line else 0
+                res.update({"wall_s": dt, "bases": nb, "bases_per_s": nb / dt,
+                            "files_written": len([f for f in os.listdir(dout) if f.endswith("_out.fasta")]),
+                            "cli_report": line[-1].strip() if line else None})
+        res["what"] = (f"python NanoReviser.py -d <{len(src)} committed fixture fast5 x {reps}, symlinked> -o <tmp> -S ecoli "
+                       f"--thread {threads} --gpus 1: own HDF5 reader, event collapse, device-side segmentation, "
+                       "model1+model2, merge, one FASTA per read; wall time of the child process, start-up included")
+        print(json.dumps(res), flush=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
 def check_world(args):
     """Before any rendezvous: a launcher's WORLD_SIZE and --gpus must agree."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -504,29 +651,41 @@ def run_dry(args):
 
 
 def run_rank(args):
+    check_world(args)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0"))
+    # the CLI helper must exist before this process makes its first HIP call (see CliHelper)
+    cli_helper = None
+    if rank == 0 and args.gpus == 1 and not args.no_extras and not args.no_cli_e2e:
+        cores, _, _ = host_cores()
+        cli_helper = CliHelper(args.cli_reps, min(cores, 16))
     import torch
     from nanoreviser_amd.engine import Reviser
     from nanoreviser_amd.weights import load_species
     from nanoreviser_amd import workload as W
 
-    check_world(args)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
-        sys.exit(f"bench.py: rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
-    d = Dist("nccl")
+    ndev = torch.cuda.device_count()
+    if args.share_device:
+        device = local_rank % ndev                     # rehearsal: several ranks on one GPU
+    elif local_rank >= ndev:
+        sys.exit(f"bench.py: rank {local_rank} has no GPU ({ndev} visible); --share-device maps ranks onto "
+                 "the devices there are")
+    else:
+        device = local_rank
+    torch.cuda.set_device(device)
+    d = Dist()
 
     T, B = args.window, args.batch
     m1, m2 = load_species(args.species)
     m1, m2 = m1.with_window(T), m2.with_window(T)
-    rv = Reviser(m1, m2, device=local_rank, batch=B, precision=args.precision)
+    rv = Reviser(m1, m2, device=device, batch=B, precision=args.precision)
     stream = torch.cuda.current_stream()
     rv.set_stream(stream.cuda_stream)
 
     sig, rd = W.synth_windows(B, T, seed=20260 + d.rank)     # each rank owns its own shard
-    dev = f"cuda:{local_rank}"
+    dev = f"cuda:{device}"
     d_sig, d_rd = torch.from_numpy(sig).to(dev), torch.from_numpy(rd).to(dev)
     p1 = torch.empty(B, 6, device=dev)
     p2 = torch.empty(B, 5, device=dev)
@@ -548,44 +707,21 @@ def run_rank(args):
     if dp > 1e-4 or not (np.array_equal(a1[:64].cpu().numpy(), b1) and np.array_equal(a2[:64].cpu().numpy(), b2)):
         sys.exit(f"bench.py: HIP path disagrees with the oracle (max|dp|={dp:.2e}); refusing to time it")
 
-    # Untimed priming.  The first unsynchronised burst of launches of a process pays a one-off ~35 ms
-    # (60 queued steps: 76-82 ms the first time, 43 ms ever after), and the chip needs ~0.2 s of load to
-    # settle on the clock it sustains; with a short --warmup both would land inside the timed region.
-    for _ in range(args.prime):
-        step()
-    sync()
-    prof_mode = 0
-    if not args.no_prof:
-        prof_mode = 1 if args.prof_all else 3            # 3: the dominant kernel, every 8th launch
-        rv.prof_enable(prof_mode)
-        rv.prof_read()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    if prof_mode:
-        rv.prof_enable(prof_mode)                        # restart the every-8th tick; drops warm-up samples
-        rv.prof_read()
-    elapsed, _ = timed_steps(d, step, sync, args.steps, 0)
-    prof = rv.prof_read() if prof_mode else {}
+    m = measure(rv, step, sync, d, args, prime=args.prime, rank0=d.rank == 0)
+    elapsed, ms_per_step = m["elapsed"], m["ms_per_step"]
     total = d.sum_int(B * args.steps)
     value = total / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
+    rank_ms = m["mine"] / args.steps * 1e3
+    rank_ms_min, rank_ms_max = d.min_float(rank_ms), d.max_float(rank_ms)
+    # the f16x2 range guard must not have fired on the benchmark's own input (a re-run would not be in `value`)
+    pending, _ = rv.saturated()
+    if d.sum_int(pending) != 0:
+        sys.exit("bench.py: the f16x2 range guard fired on the synthetic workload; the timed steps are not valid")
 
-    # untimed pass: every kernel bracketed (7 event records per step would perturb the timed region)
-    kernel_us = {}
-    if prof_mode and d.rank == 0:
-        rv.prof_enable(1)
-        rv.prof_read()
-        for _ in range(max(8, min(args.steps, 32))):
-            step()
-        sync()
-        kernel_us = {k: (ms / max(c, 1)) * 1e3 for k, (ms, c) in rv.prof_read().items() if c > 0}
-    rv.prof_enable(0)
-
-    peak, peak_note = mode_peak(args.precision)
     out = {
         "metric": "bases revised/sec (whole node)", "value": value, "unit": "bases/s",
         "n_gpus": args.gpus, "world_size": d.world, "steps": args.steps, "warmup": args.warmup,
+        "prime": args.prime,
         "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE[args.precision],
@@ -596,50 +732,25 @@ def run_rank(args):
                         + ("; T=13 uses the shipped weights + seeded synthetic (78,16) feature kernel" if T != 11 else ""),
             "species": args.species, "window": T, "batch_windows_per_gpu": B,
             "precision": args.precision,
-            "parallelism": f"read/window-sharded x{args.gpus}, no collectives",
+            "parallelism": f"read/window-sharded x{args.gpus}, no collectives; control plane on gloo (CPU tensors)"
+                           + (f"; --share-device: {d.world} ranks on {ndev} device(s)" if args.share_device else ""),
             "parity_guard_max_abs_dp": dp,
+            "prime_note": f"{args.prime} untimed priming steps precede the {args.warmup} warm-up steps (clock settling)",
         },
+        "f16x2_range_guard": {"pending_after_timed_region": 0},
+        "rank_ms_per_step": {"min": rank_ms_min, "max": rank_ms_max},
     }
     if d.rank == 0:
-        if prof:
-            names = list(prof.keys())
-            k3 = names[3]
-            if prof[k3][1] > 0:
-                avg_s = prof[k3][0] / prof[k3][1] * 1e-3
-                where = "hipEvent pairs on the launch stream inside the timed region" + \
-                    (", every 8th launch bracketed" if prof_mode == 3 else "")
-                n_l = prof[k3][1]
-            else:                                             # fewer than one sampled launch: use the untimed pass
-                avg_s = kernel_us[k3] * 1e-6
-                where, n_l = "hipEvent pairs on the launch stream, untimed pass right after the timed region", 0
-            fl = flop_lstm3_launch(T, B, executed=True)
-            ach = fl / avg_s / 1e12
-            kname = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
-                     "f16x2": "lstm_h2s_kernel<32,16,128,2,1,2> (16x16x32 f16 tiles)"}[args.precision]
-            out["roofline"] = {
-                "kernel": f"{kname} ({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
-                "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": load_traffic(T, B, args.precision),
-                "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": n_l,
-                "avg_launch_us_untimed_pass": kernel_us.get(k3),
-                "timing": where, "peak_note": peak_note,
-                "executed_tflops": ach * PRODUCTS[args.precision],
-                "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-            }
-            whole = flop_per_window(T) * B / (ms_per_step * 1e-3) / 1e12
-            out["roofline_whole_step"] = {"achieved": whole, "peak": peak, "unit": "TFLOP/s",
-                                          "frac": whole / peak,
-                                          "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
-                                          "flop_per_window": flop_per_window(T)}
-            out["kernel_us"] = kernel_us
-            out["kernel_us_sum"] = sum(kernel_us.values())
+        out.update(roofline_blocks(args, T, B, args.precision, m))
     rv.close()
     if d.rank == 0 and args.gpus == 1 and not args.no_extras:
         del d_sig, d_rd
         try:
-            out.update(extras(args, torch, dev, local_rank, m1, m2, sig, rd, ms_per_step))
+            out.update(extras(args, torch, dev, device, m1, m2, sig, rd, ms_per_step, cli_helper))
         except Exception as e:                               # never lose the main line to a secondary block
             out["extras_error"] = repr(e)
+    if cli_helper is not None:
+        cli_helper.close()
     if d.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(m1, m2, T, sig, rd)
     if d.rank == 0:
@@ -666,8 +777,16 @@ def main(argv=None):
                     help="time every kernel INSIDE the timed region (7 event records per step)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo run of the launch + sharding + timing control path (no engine)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rank r runs on device r %% device_count (rehearse N ranks on fewer GPUs; never the default)")
+    ap.add_argument("--no-cli-e2e", action="store_true", help="skip host_inclusive.cli_e2e (the CLI in a child process)")
+    ap.add_argument("--cli-reps", type=int, default=1000, help="cli_e2e: copies of each committed fixture read")
+    ap.add_argument("--cli-threads", type=int, default=16, help=argparse.SUPPRESS)
+    ap.add_argument("--cli-e2e-helper", action="store_true", help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
+    if args.cli_e2e_helper:
+        return cli_e2e_helper(args.cli_reps, args.cli_threads)
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

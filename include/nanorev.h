@@ -121,6 +121,11 @@ int nrv_get_batch(nrv_handle* h);
  *                    from the six term pairs that matter, on the bf16 matrix pipe; ~1.5x f32 mode;
  *   NRV_PREC_F32     plain f32 matrix instructions.
  * The convolutions, the first Bi-LSTM (6->16) and the per-window tail are f32 in every mode.
+ * Range of NRV_PREC_F16X2: every activation has a static bound except the signal branch (the reference
+ * normalises samples as (raw - median) / MAD without clipping, preprocessing.py:120-131, and computes in
+ * f32, nanorevcnn.py:24-37, so spike samples and tiny MADs have a well-defined answer).  The f16x2 signal
+ * branch represents |S| < 1023; a launch group that leaves that range (or carries a NaN / Inf sample)
+ * is detected on the device and NEVER returned as is: see nrv_saturated.
  * Takes effect from the next call.  The environment variable NRV_PRECISION=f32|bf16x3|f16x2 sets the
  * mode a new handle starts in. */
 #define NRV_PREC_F32 0
@@ -128,6 +133,16 @@ int nrv_get_batch(nrv_handle* h);
 #define NRV_PREC_F16X2 2
 int nrv_set_precision(nrv_handle* h, int mode);
 int nrv_get_precision(nrv_handle* h);
+
+/* Range guard of NRV_PREC_F16X2 (no-op in the other modes, which keep f32 buffers).
+ *   Host-pointer entry points (nrv_predict, nrv_predict_read, nrv_predict_reads_raw): a pipeline stage whose
+ *   signal branch left the f16 range is re-run on the NRV_PREC_F32 kernels before its results are handed over;
+ *   *reruns counts such stages since nrv_create (informational - the results are already the f32 mode's).
+ *   Device-pointer entry points (asynchronous): *pending is non-zero when a launch group enqueued since the
+ *   previous nrv_saturated call left the range; the outputs of those calls must be discarded and the calls
+ *   repeated after nrv_set_precision(h, NRV_PREC_F32) (engine.Reviser.predict_device_checked does that).
+ *   Synchronises the handle's stream and clears the pending count.  Either pointer may be NULL. */
+int nrv_saturated(nrv_handle* h, int64_t* pending, int64_t* reruns);
 
 /* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
 int nrv_set_stream(nrv_handle* h, void* hip_stream);

@@ -214,15 +214,23 @@ def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
         text = hs.fastq_record(fast5_fn, list(seq), list(qual if qual is not None else "#" * len(seq)))
     else:
         text = hs.fasta_record(fast5_fn, list(seq))
-    with open(out_name(args.output_dir, fast5_fn, args.output_format), "w") as fp:
+    # atomic: a worker killed mid-write leaves a stray temporary, never a truncated <read>_out file
+    dst = out_name(args.output_dir, fast5_fn, args.output_format)
+    tmp = f"{dst}.tmp{os.getpid()}"
+    with open(tmp, "w") as fp:
         fp.write(text)
+    os.replace(tmp, dst)
 
 
-def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None]) -> dict:
+def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None],
+                  on_file: Optional[Callable[[str, bool], None]] = None) -> dict:
     """Revise `files` (names inside args.fast5_base_dir) with one engine.  The host stage (HDF5
     parsing, event collapse, signal segmentation) runs in worker PROCESSES (--thread of them, capped
-    at the core count) that stay a bounded number of reads ahead of the device."""
+    at the core count) that stay a bounded number of reads ahead of the device.
+    on_file(fn, revised): called once per file when its output is final (revised, or the original
+    basecalls after a failure; revised=False also for files that could not be parsed at all)."""
     stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
+    note = on_file or (lambda fn, ok: None)
     nworkers = max(1, min(int(args.thread), os.cpu_count() or 1, 32, max(1, len(files))))
     jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup)
             for fn in files]
@@ -255,6 +263,7 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                 write_read(args, fn, orig, None)
         except Exception as e2:
             log(f"[！！！Error] stroring : {fn.split('.')[0]}_out.{args.output_format}...... {e2}")
+        note(fn, False)
 
     want_qual = args.output_format == "fastq"
 
@@ -272,6 +281,7 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                     log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved......")
                 else:
                     log("INFO Congratulations, NanoReviser is installed properly")
+                note(fn, True)
             except Exception as e:
                 fallback(fn, rt, fq, e)
 
@@ -304,6 +314,7 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             if rt is None:
                 log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {err}")
                 stats["failed"].append(fn)
+                note(fn, False)
                 continue
             if err is not None:
                 fallback(fn, rt, fq, err)
@@ -319,6 +330,12 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             inflight.append(eng.submit(run_batch, batch))
         while inflight:
             inflight.popleft().result().result()
+    sat = getattr(reviser, "saturated", None)
+    if callable(sat):                                 # f16x2 range guard: stages re-run on the f32 kernels
+        stats["range_reruns"] = int(sat()[1])
+        if stats["range_reruns"]:
+            log(f"[s:::] {stats['range_reruns']} device stage(s) held out-of-range signal (spikes / tiny MAD) "
+                "and were computed on the f32 kernels")
     return stats
 
 
@@ -329,23 +346,24 @@ def _default_factory(args, device: int):
 
 
 def _worker(rank: int, world: int, args, files: List[str], q, factory=None):
+    """One GPU worker.  Streams a ("file", rank, fn, revised) record through the queue as each file's output
+    becomes final, so that the parent knows exactly which files are done should this process die."""
     try:
         rv = (factory or _default_factory)(args, rank)
-        st = process_files(args, files, rv, print)
+        st = process_files(args, files, rv, print, on_file=lambda fn, ok: q.put(("file", rank, fn, bool(ok))))
         rv.close()
-        q.put((rank, st, None))
+        q.put(("done", rank, st, None))
     except BaseException as e:           # engine could not be created: loud, no silent fallback
-        q.put((rank, None, repr(e)))
+        q.put(("done", rank, None, repr(e)))
 
 
 def write_originals(args, files: Sequence[str], log: Callable[[str], None]) -> List[str]:
     """The failure contract for reads whose WORKER is gone (NanoReviser.py:146-152 / :173-179): every
-    file of the shard that has no output yet gets its original basecalls written by this process.
+    file in `files` - the ones the dead worker never reported as final - gets its original basecalls
+    written by this process (atomically, replacing whatever an earlier run left under that name).
     Returns the files handled (all of them count as failed reads)."""
     done = []
     for fn in files:
-        if os.path.exists(out_name(args.output_dir, fn, args.output_format)):
-            continue
         done.append(fn)
         try:
             rd, fq = parse_read(os.path.join(args.fast5_base_dir, fn), args.basecall_group, args.basecall_subgroup)
@@ -364,7 +382,8 @@ def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2
     file).  The parent never blocks on the result queue alone: a worker that dies hard - a HIP memory
     fault aborts the process, a segfault, the OOM killer - posts nothing, so liveness is polled next to
     the queue.  The other workers finish their own shards (reads are independent).
-    Returns [(rank, stats or None, error or None)]."""
+    Returns [(rank, stats or None, error or None, files)] with files = {fn: revised} for every file the
+    worker reported final before it ended (file existence is never used as evidence)."""
     import multiprocessing as mp
     import queue as _q
     ctx = mp.get_context("spawn")
@@ -374,12 +393,17 @@ def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2
     for pr in procs:
         pr.start()
     res = {}
+    files = [dict() for _ in range(world)]
 
     def drain(timeout):
         try:
             while True:
-                rank, st, err = q.get(timeout=timeout)
-                res[rank] = (rank, st, err)
+                msg = q.get(timeout=timeout)
+                if msg[0] == "file":
+                    files[msg[1]][msg[2]] = msg[3]
+                else:
+                    _, rank, st, err = msg
+                    res[rank] = (rank, st, err)
                 timeout = 0.0
         except _q.Empty:
             pass
@@ -388,14 +412,14 @@ def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2
         drain(poll_s)
         for r, pr in enumerate(procs):
             if r not in res and not pr.is_alive():
-                drain(0.5)                            # its last message may still be in the pipe
+                drain(0.5)                            # its last messages may still be in the pipe
                 if r not in res:
                     res[r] = (r, None, f"worker {r} died without reporting (exit code {pr.exitcode})")
     for pr in procs:
         pr.join(30)
         if pr.is_alive():
             pr.terminate()
-    return [res[r] for r in range(world)]
+    return [res[r] + (files[r],) for r in range(world)]
 
 
 def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone: bool = False,
@@ -441,12 +465,15 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         else:
             shards = [[names[i] for i in parts[r]] for r in range(world)]
             res = run_workers(args, shards, worker_factory)
-            stats = [s for _, s, _ in res if s is not None]
-            for r, s_, e in res:
+            stats = [s for _, s, _, _ in res if s is not None]
+            for r, s_, e, final in res:
                 if s_ is None:                        # the shard's files still get an output + a failed_reads entry
                     print(f"[！！！Error] GPU worker {r} failed: {e}; writing the original basecalls of its "
                           f"unfinished reads", file=sys.stderr)
-                    lost = write_originals(args, shards[r], print)
+                    # what the worker reported final stays (its failed reads keep their failed_reads entry);
+                    # everything else - started or not, whatever lies on disk - is written unrevised
+                    lost = write_originals(args, [f for f in shards[r] if f not in final], print)
+                    lost += [f for f, ok in final.items() if not ok]
                     stats.append({"reads": len(shards[r]), "bases": 0, "failed": lost, "host_s": 0.0, "engine_s": 0.0})
                     rc = 3
     failed = [f for s in stats for f in s["failed"]]

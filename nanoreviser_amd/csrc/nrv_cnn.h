@@ -114,13 +114,9 @@ __device__ __forceinline__ void conv_positions(const float* __restrict__ cw, con
 // more than twice: wave (nh, kh) holds its 13 (12) k-blocks of split weights in registers, the kh = 1
 // wave hands its partial tile to its partner through a double-buffered 4 KB LDS slab, and the
 // partner adds it one iteration later (behind the tile barrier that exists anyway).
-// OUT_SPLIT (f16x2 mode, SPLIT only): the 64 outputs leave as f16 split planes [kb 4][term][half][32][8 f16]
-// (nrv_lstm_f16x2.h) instead of the f32 tile; their power-of-two scale is already in dsplit / dbias.
-// They are the one activation without a static bound, so they are clamped to the f16 range first
-// (|S| > 2^9 at the default scale: garbage input; the reference would produce garbage too).
-template <bool SPLIT, bool OUT_SPLIT = false>
+// The f16x2 mode has its own signal-branch kernel (cnn_h2_kernel, nrv_cnn_f16x2.h).
+template <bool SPLIT>
 __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
-  static_assert(SPLIT || !OUT_SPLIT, "split-plane output is implemented for the bf16x3 dense layer");
   constexpr int PLANE = 32 * 4 + 4;         // floats per kq plane of the image (+4: conflict-free)
   constexpr int IMG = 100 * PLANE;
   __shared__ __attribute__((aligned(16))) float img[2 * IMG];
@@ -212,18 +208,7 @@ __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-          const float v = prev[reg] + ps[reg * 64];
-          if constexpr (OUT_SPLIT) {
-            const float vc = __builtin_fminf(__builtin_fmaxf(v, -60000.f), 60000.f);
-            const _Float16 hi = (_Float16)vc;
-            const _Float16 lo = (_Float16)(vc - (float)hi);
-            // unit u: k-block u>>4, half (u>>3)&1, element u&7; chunk = 4*kb + 2*term + half
-            _Float16* d16 = (_Float16*)(dst + ((u >> 4) * 4 + ((u >> 3) & 1)) * 128 + row * 4) + (u & 7);
-            d16[0] = hi;
-            d16[2 * 128 * 2] = lo;                       // + two chunks (term 1), in f16 units
-          } else {
-            dst[(u >> 2) * 128 + row * 4 + (u & 3)] = v;
-          }
+          dst[(u >> 2) * 128 + row * 4 + (u & 3)] = prev[reg] + ps[reg * 64];
         }
       };
       for (int i = 0; i <= nloc; ++i) {

@@ -16,8 +16,8 @@ namespace nrv {
 //     them convolving (3-4 positions per thread instead of 6-7): every SIMD holds two conv waves (and
 //     one matrix wave) and the same instructions issue at twice the rate;
 //   * splitting an activation once in its PRODUCER is 3x cheaper than splitting it in every consumer:
-//     the conv threads store the 400 features of an event already scaled (x 2^6, clamped to the f16
-//     range) and split into two f16 terms, as the A fragments the dense layer reads -
+//     the conv threads store the 400 features of an event already scaled (x 2^6) and split into two
+//     f16 terms, as the A fragments the dense layer reads -
 //     [k-block 26][term][half][32 events][8 f16], one 16-byte LDS store per (event, position, term),
 //     exactly the two stores the f32 image needed.  The four matrix waves then run the dense layer
 //     with NO VALU work in the loop: wave ct owns 16 output columns as v_mfma_f32_16x16x32_f16 tiles
@@ -35,6 +35,15 @@ namespace nrv {
 // cnn_kernel<true,true> (4 conv waves, bf16x3 dense): 90 us.
 // Persistent: one workgroup per CU and model, tile i is convolved while tile i-1 is multiplied; one
 // barrier per tile.  Output: f16 split planes of S x 2^6 (the layout lstm_h2o_kernel reads).
+//
+// RANGE GUARD.  The conv features and S are the one activation of the f16x2 mode without a static bound
+// (the reference normalises samples as (raw - median) / MAD without any clipping, preprocessing.py:120-131,
+// so a spike sample or a tiny MAD gives arbitrarily large inputs, and f32 arithmetic gives them a
+// well-defined answer).  Nothing is clamped here: a feature beyond the f16 range becomes an f16 infinity, a
+// NaN sample a NaN, either makes every one of the event's 64 outputs non-finite, and the matrix role's
+// epilogue - which sees every output anyway - counts outputs that are not |S x 2^6| <= 65504 into *sat.
+// The host re-runs a launch group with a non-zero count on the f32 kernels (nrv_api.hip), so the f16x2
+// mode never returns a result that differs from the f32 mode's for out-of-range input.
 // ---------------------------------------------------------------------------------------
 struct CnnH2ModelParams {
   const float* conv;      // 24 w1[k][o], 8 b1, 8 s1, 8 h1, 192 w2[k][c][o], 8 b2, 8 s2 x 2^6, 8 h2 x 2^6  (=264)
@@ -49,6 +58,7 @@ struct CnnH2Args {
   int T;                  // window mode: T; event mode: 1
   int n_rows;             // windows (window mode) or events (event mode)
   int n_tiles;            // 32-event tiles to process (per model)
+  unsigned* sat;          // range guard: += waves that produced an output outside the f16 range (or NaN)
 };
 
 constexpr float kImgScale = 64.0f;          // 2^6: conv features in the LDS image and S in HBM
@@ -134,8 +144,7 @@ __device__ __forceinline__ void conv_positions_h2(const lds_f32* cw, const float
     for (int o = 0; o < 8; ++o) {
       float v = __builtin_fmaxf(acc[q][o], 0.f);
       v = __builtin_fmaf(v, s2[o], h2[o] + xs);
-      v = __builtin_fminf(__builtin_fmaxf(v, -60000.f), 60000.f);
-      const _Float16 hh = (_Float16)v;
+      const _Float16 hh = (_Float16)v;             // beyond the f16 range: +-inf, caught by the matrix role's guard
       hi[o] = hh;
       lo[o] = (_Float16)(v - (float)hh);
     }
@@ -233,6 +242,7 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
         bw[k][tm] = *(const f16x8*)((const char*)P.dsplit + ((size_t)((k * 4 + ct) * 2 + tm) * 64 + lane) * 16);
     const float bias = P.dbias[ct * 16 + n16];
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};           // lo*hi, hi*lo, hi*hi
+    bool bad = false;                              // range guard: an output that is not |v| <= f16 max (NaN included)
     __syncthreads();                               // tile 0 is being convolved
     for (int i = 1; i <= nloc; ++i) {
       {
@@ -272,8 +282,8 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int row = rh * 16 + 4 * kg + q;
-            float v = acc[rh][q] * kDenseDescale;
-            v = __builtin_fminf(__builtin_fmaxf(v, -60000.f), 60000.f);
+            const float v = acc[rh][q] * kDenseDescale;
+            bad |= !(__builtin_fabsf(v) <= 65504.f);
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
             _Float16* d16 = (_Float16*)(dst + ((u >> 4) * 4 + ((u >> 3) & 1)) * 128 + row * 4) + (u & 7);
@@ -283,6 +293,7 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
       }
       __syncthreads();
     }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(args.sat, 1u);
   }
 }
 

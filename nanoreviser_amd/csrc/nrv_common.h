@@ -53,6 +53,10 @@ __device__ __forceinline__ float hard_sigmoid(float x) {
 }
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ReLU of the dense layers: NaN in, NaN out, as NumPy / the oracle (and IEEE comparison semantics) have it -
+// v_max_f32 would return the non-NaN operand and turn a poisoned window into finite garbage.
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 template <int ACT>
 __device__ __forceinline__ float gate_act(float x) {
   if constexpr (ACT == 0) return hard_sigmoid(x);

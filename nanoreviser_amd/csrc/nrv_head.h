@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
     const int u = nt * 32 + l31;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg)
-      im[(u >> 2) * PLANE + acc_row(reg, lane) * 4 + (u & 3)] = __builtin_fmaxf(acc[nt][reg], 0.f);
+      im[(u >> 2) * PLANE + acc_row(reg, lane) * 4 + (u & 3)] = relu_nan(acc[nt][reg]);
   }
   // dense2: 128 -> 32 (the same wave wrote the image; DS operations of one wave complete in order)
   wave_lds_fence();
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
   wave_lds_fence();                                       // dense2's reads of the image before it is overwritten
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg)
-    im[(l31 >> 2) * PLANE + acc_row(reg, lane) * 4 + (l31 & 3)] = __builtin_fmaxf(a2[reg], 0.f);
+    im[(l31 >> 2) * PLANE + acc_row(reg, lane) * 4 + (l31 & 3)] = relu_nan(a2[reg]);
   wave_lds_fence();
   // main_out: 32 -> 6 (padded to 32 columns)
   f32x16 a3 = splat16(P.mobias[l31]);
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) head_mlp_kernel(const HeadArgs args) {
   if (l31 < 8) {
     float* dst = P.mo + (size_t)bt * 32 * 8 + l31;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) dst[acc_row(reg, lane) * 8] = __builtin_fmaxf(a3[reg], 0.f);
+    for (int reg = 0; reg < 16; ++reg) dst[acc_row(reg, lane) * 8] = relu_nan(a3[reg]);
   }
 }
 
@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(256) head_mlp_split_kernel(const HeadSplitArgs
   auto relu8 = [&](const f32x16& z, int base, f32x4& lo, f32x4& hi) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      lo[j] = __builtin_fmaxf(z[base + j], 0.f);
-      hi[j] = __builtin_fmaxf(z[base + 4 + j], 0.f);
+      lo[j] = relu_nan(z[base + j]);
+      hi[j] = relu_nan(z[base + 4 + j]);
     }
   };
   const unsigned av = l31 * 16 + half * 1024;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) head_mlp_split_kernel(const HeadSplitArgs
     // lane (row, half h) holds output features 4h..4h+3 in registers 0..3
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaxf(a3[j], 0.f);
+    for (int j = 0; j < 4; ++j) o[j] = relu_nan(a3[j]);
     *(f32x4*)(P.mo + ((size_t)u * 32 + l31) * 8 + 4 * half) = o;
   }
 }
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) head_final_kernel(const HeadArgs args) {
       v = __builtin_fmaf(x[2], w[2], v);
       v = __builtin_fmaf(x[3], w[3], v);
     }
-    featv[r * 17 + f] = __builtin_fmaxf(v, 0.f);
+    featv[r * 17 + f] = relu_nan(v);
   }
   __syncthreads();
   const int C = P.n_class;

@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
     f32x4 lo, hi;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      lo[j] = __builtin_fmaxf(z[base + j] * c, 0.f);
-      hi[j] = __builtin_fmaxf(z[base + 4 + j] * c, 0.f);
+      lo[j] = relu_nan(z[base + j] * c);
+      hi[j] = relu_nan(z[base + 4 + j] * c);
     }
     return split2(lo, hi);
   };
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
       // lane (row, half h) holds output features 4h..4h+3 in registers 0..3
       f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaxf(a3[j] * P.c3o, 0.f);
+      for (int j = 0; j < 4; ++j) o[j] = relu_nan(a3[j] * P.c3o);
       *(f32x4*)(mo + (t * 32 + l31) * 8 + 4 * half) = o;
     }
     __syncthreads();
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
         v = __builtin_fmaf(x1[0], w1[0], v);
         v = __builtin_fmaf(x1[1], w1[1], v);
       }
-      featv[r * 17 + f] = __builtin_fmaxf(v, 0.f);
+      featv[r * 17 + f] = relu_nan(v);
     }
     __syncthreads();
     const int C = P.n_class;

@@ -42,8 +42,8 @@ namespace nrv {
 // Structure: as lstm_split_kernel (a wave owns 32 hidden units x 4 gates x R row tiles, c in
 // registers, h through a double-buffered LDS image, one barrier per step), but the k-blocks of a
 // step are FULLY unrolled: ring slots, operand types (pre-split input block / raw recurrent block)
-// and the counted waits are static, weights are requested LB and activations LA k-blocks ahead, and
-// the requests run across the step boundary (the first blocks of step s+1 do not depend on h_s).
+// and the counted waits are static, weights and activations are requested a fixed number of entries
+// ahead, and the requests run across the step boundary (the first blocks of step s+1 do not depend on h_s).
 // ---------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -95,270 +95,12 @@ struct LstmH2Args {
   int n_blk;
 };
 
-// grid = lstm_grid(ceil(tiles/(R*WR))), block = 64*NG*WR.  K0 = 4*KQ0, K1 = 4*KQ1, H multiples of 16.
-// LB / LA: k-blocks of lead of the weight / activation requests.
-template <int KQ0, int KQ1, int H, int R, int WR, int ACT, bool OUT_F32, int LB, int LA>
-__global__ void __launch_bounds__(64 * ((H + 31) / 32) * WR)
-lstm_h2_kernel(const LstmH2Args args) {
-  constexpr int NG = (H + 31) / 32;
-  constexpr int KB0 = KQ0 / 4, KB1 = KQ1 / 4, KB_IN = KB0 + KB1, KB_REC = H / 16, KB = KB_IN + KB_REC;
-  constexpr int ROWS = 32 * R * WR;
-  constexpr int PLANE = ROWS * 4 + 4;
-  constexpr int HBUF = (NG * 32 / 4) * PLANE;
-  constexpr int NTHREADS = 64 * NG * WR;
-  constexpr int NB = LB + 1, NA = LA + 1;
-  static_assert(KQ0 % 4 == 0 && KQ1 % 4 == 0 && H % 16 == 0, "K must come in blocks of 16");
-  static_assert(LA <= KB_IN && LB <= KB_IN && LA >= 1 && LB >= 1, "leads must stay inside the input blocks");
-
-  // At R = 2 the weight and activation rings (LB = LA = 3) take 192 of the 256 VGPRs that VALU
-  // instructions can address; with the cell state (32 registers) on top hipcc spills, and a spill
-  // reload waits on vmcnt(0) - behind the whole prefetch queue.  The cell state then lives in LDS
-  // ([cell][thread]: conflict-free, 32 KB).
-  constexpr bool CLDS = R >= 2;
-  __shared__ __attribute__((aligned(16))) float hbuf[2 * HBUF];
-  __shared__ __attribute__((aligned(16))) float bnl[2 * H];
-  __shared__ float cl[CLDS ? 16 * R * NTHREADS : 1];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hg = wave % NG, wr = wave / NG;
-  const int half = lane >> 5, l31 = lane & 31;
-  const LstmBlock blk = lstm_block();
-  if (blk.rowblk >= args.n_blk) return;
-  const int dir = blk.dir;
-  const LstmH2ModelParams& P = args.m[blk.model];
-  const int T = args.T;
-  const int row0 = blk.rowblk * ROWS + wr * (32 * R);
-  const int lrow0 = wr * (32 * R);
-
-  // weights: [kb][gate][term] x 1 KiB, buffer-addressed
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(
-      (const char*)P.wsplit + ((size_t)(dir * NG + hg) * KB) * (4 * 2 * 1024), KB * 4 * 2 * 1024);
-  const unsigned wlane = lane * 16;
-  const float* bp = P.bias + (size_t)(dir * NG + hg) * 4 * 32 + l31;
-  const float bias4[4] = {bp[0], bp[32], bp[64], bp[96]};
-  const float dsc = P.descale, dsc02 = 0.2f * dsc, dsc2 = 2.885390081777927f * dsc;
-  const int u = hg * 32 + l31;
-  const int hw_off = (u >> 2) * PLANE + (u & 3) + (lrow0 + 4 * half) * 4;
-  const int hp_off = (2 * half) * PLANE + (lrow0 + l31) * 4;
-
-  for (int i = threadIdx.x; i < 2 * H; i += NTHREADS)
-    bnl[i] = i < H ? P.out_scale[dir * H + i] : P.out_shift[dir * H + i - H];
-  __syncthreads();
-
-  f32x16 c[CLDS ? 1 : R];
-  if constexpr (CLDS) {
-#pragma unroll
-    for (int i = 0; i < 16 * R; ++i) cl[i * NTHREADS + threadIdx.x] = 0.f;
-  } else {
-#pragma unroll
-    for (int r = 0; r < R; ++r) c[r] = splat16(0.0f);
-  }
-
-  // Input addressing of one timestep: per row tile a buffer resource and a lane offset per segment.
-  struct ABase {
-    __amdgpu_buffer_rsrc_t r0[R], r1[R];
-    unsigned v0[R], v1[R];
-  };
-  auto mk_base = [&](int t) __attribute__((always_inline)) {
-    ABase ab;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      ab.r0[r] = make_rsrc(P.in0.ubase(row0 + r * 32, t), 0xffffffffu);
-      ab.v0[r] = P.in0.voff(row0 + r * 32, t, l31, half) * 4;              // chunk 4kb + 2 term + half
-      if constexpr (KQ1 > 0) {
-        ab.r1[r] = make_rsrc(P.in1.ubase(row0 + r * 32, t), 0xffffffffu);
-        ab.v1[r] = P.in1.voff(row0 + r * 32, t, l31, half) * 4;
-      } else {
-        ab.r1[r] = ab.r0[r];
-        ab.v1[r] = 0;
-      }
-    }
-    return ab;
-  };
-  auto loadB = [&](int kb, f16x8 (&bb)[4][2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-        bb[g][tm] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, ((kb * 4 + g) * 2 + tm) * 1024));
-  };
-  // A registers of one (k-block, row tile): the two f16 terms of an input block, or the raw f32
-  // chunks of a recurrent block (same 8 registers either way)
-  struct AReg { f32x4 v[2]; };
-  auto loadA_in = [&](const ABase& ab, int kb, int r, AReg& a) __attribute__((always_inline)) {
-    if (KQ1 == 0 || kb < KB0) {
-      a.v[0] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048);
-      a.v[1] = buf_load16(ab.r0[r], ab.v0[r], kb * 2048 + 1024);
-    } else {
-      a.v[0] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048);
-      a.v[1] = buf_load16(ab.r1[r], ab.v1[r], (kb - KB0) * 2048 + 1024);
-    }
-  };
-
-  AReg a[NA][R];
-  f16x8 b[NB][4][2];
-  Split2 S[2];
-  ABase cur = mk_base(dir ? T - 1 : 0);
-#pragma unroll
-  for (int i = 0; i < LB; ++i) loadB(i, b[i]);
-#pragma unroll
-  for (int i = 0; i < LA; ++i)
-#pragma unroll
-    for (int r = 0; r < R; ++r) loadA_in(cur, i, r, a[i][r]);
-
-  // One timestep.  FIRST: h_{-1} = 0, the recurrent blocks do not exist.  Ring slots are taken modulo
-  // the ring size from block 0 of the step; a step requests as many blocks as it consumes (its own tail
-  // + the head of the next step), so with KB and KB_IN multiples of both ring sizes block 0 of every
-  // step sits in slot 0 and ONE instantiation of the body (plus the first step's) serves all steps.
-  static_assert(KB % NB == 0 && KB_IN % NB == 0 && KB % NA == 0 && KB_IN % NA == 0,
-                "ring sizes must divide the k-block counts");
-  auto step = [&](auto first_tag, int s, const ABase& nxt) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int OB = 0, OA = 0;
-    constexpr int KBS = FIRST ? KB_IN : KB;
-    const float* hcur = hbuf + (s & 1) * HBUF;
-    float* hnxt = hbuf + ((s + 1) & 1) * HBUF;
-    const float* hp = hcur + hp_off;
-
-    f32x16 acc[4][R];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[g][r] = splat16(bias4[g]);
-
-#pragma unroll
-    for (int kb = 0; kb < KBS; ++kb) {
-      // ---- requests: weights of block kb + LB, activations of block kb + LA (past the end of the
-      // step: the same blocks of the next step, which do not depend on h_s)
-      {
-        const int kw = kb + LB;
-        loadB(kw < KBS ? kw : kw - KBS, b[(OB + kw) % NB]);
-        const int ka = kb + LA;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          AReg& dst = a[(OA + ka) % NA][r];
-          if (ka < KB_IN) loadA_in(cur, ka, r, dst);
-          else if (ka < KBS) {
-            const float* qh = hp + (ka - KB_IN) * 4 * PLANE + r * 128;
-            dst.v[0] = *(const f32x4*)(qh);
-            dst.v[1] = *(const f32x4*)(qh + PLANE);
-          } else loadA_in(nxt, ka - KBS, r, dst);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int q = kb * R + r;                         // unit number inside the step
-        const bool raw = kb >= KB_IN;                     // this unit's operand needs the split
-        // the NEXT unit's split, if it is a recurrent one, is produced in this unit's matrix shadow
-        const int kbn = (r + 1 < R) ? kb : kb + 1, rn = (r + 1 < R) ? r + 1 : 0;
-        const bool raw_n = kbn >= KB_IN && kbn < KBS;
-        if (raw_n) S[(q + 1) & 1] = split2(a[(OA + kbn) % NA][rn].v[0], a[(OA + kbn) % NA][rn].v[1]);
-        f16x8 at[2];
-        if (raw) { at[0] = S[q & 1].t[0]; at[1] = S[q & 1].t[1]; }
-        else {
-          at[0] = __builtin_bit_cast(f16x8, a[(OA + kb) % NA][r].v[0]);
-          at[1] = __builtin_bit_cast(f16x8, a[(OA + kb) % NA][r].v[1]);
-        }
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};          // lo*hi, hi*lo, hi*hi
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[g][r] = mfma_f16(at[PA[pr]], b[(OB + kb) % NB][g][PB[pr]], acc[g][r]);
-        if (raw_n) {
-#pragma unroll
-          for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two VALU ops of the next unit's split
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    // gates, h_t * 2^13 -> LDS
-    {
-      float* hw = hnxt + hw_off;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const float ig = gate_act_scaled<ACT>(acc[0][r][reg], dsc, dsc02);
-          const float fg = gate_act_scaled<ACT>(acc[1][r][reg], dsc, dsc02);
-          const float gg = tanh_fast_scaled(acc[2][r][reg], dsc2);
-          const float og = gate_act_scaled<ACT>(acc[3][r][reg], dsc, dsc02);
-          float cprev;
-          if constexpr (CLDS) cprev = cl[(r * 16 + reg) * NTHREADS + threadIdx.x];
-          else cprev = c[r][reg];
-          const float cn = __builtin_fmaf(fg, cprev, ig * gg);
-          if constexpr (CLDS) cl[(r * 16 + reg) * NTHREADS + threadIdx.x] = cn;
-          else c[r][reg] = cn;
-          hw[(r * 32 + (reg & 3) + 8 * (reg >> 2)) * 4] = (og * tanh_fast(cn)) * kHScale;
-          if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the accumulator read-out local
-        }
-    }
-    __syncthreads();
-    // h_t (+BatchNorm, output scale) -> global
-    const int t = dir ? (T - 1 - s) : s;
-    if constexpr (OUT_F32) {
-      constexpr int KQH = H / 4;
-      constexpr int ITEMS = KQH * ROWS;
-      for (int it = threadIdx.x; it < ITEMS; it += NTHREADS) {
-        const int kq = it / ROWS, rr = it % ROWS;
-        f32x4 v = *(const f32x4*)(hnxt + kq * PLANE + rr * 4);
-        const f32x4 sc = *(const f32x4*)(bnl + kq * 4);
-        const f32x4 sh = *(const f32x4*)(bnl + H + kq * 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = v[k] * sc[k] + sh[k];
-        const int tile = blk.rowblk * (R * WR) + rr / 32;
-        float* dst = P.out + ((size_t)(tile * T + t) * (2 * KQH) + dir * KQH + kq) * 128 + (rr & 31) * 4;
-        *(f32x4*)dst = v;
-      }
-    } else {
-      constexpr int KBH = H / 16;                       // k-blocks this direction contributes
-      constexpr int ITEMS = KBH * 2 * ROWS;             // (k-block, half, row): 8 features each
-      for (int it = threadIdx.x; it < ITEMS; it += NTHREADS) {
-        const int kbh = it / ROWS, rr = it % ROWS;      // kbh = 2*kbo + hf
-        const int kq = 2 * kbh;                         // features 8*kbh .. 8*kbh + 7
-        const f32x4 x0 = *(const f32x4*)(hnxt + kq * PLANE + rr * 4);
-        const f32x4 x1 = *(const f32x4*)(hnxt + (kq + 1) * PLANE + rr * 4);
-        const f32x4 s0 = *(const f32x4*)(bnl + kq * 4), s1 = *(const f32x4*)(bnl + kq * 4 + 4);
-        const f32x4 h0 = *(const f32x4*)(bnl + H + kq * 4), h1 = *(const f32x4*)(bnl + H + kq * 4 + 4);
-        f32x4 v0, v1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v0[k] = x0[k] * s0[k] + h0[k]; v1[k] = x1[k] * s1[k] + h1[k]; }
-        const Split2 o = split2(v0, v1);
-        const int tile = blk.rowblk * (R * WR) + rr / 32;
-        const int kbo = kbh >> 1, hf = kbh & 1;
-        // chunk index 4*kb + 2*term + half, kb counted over both directions' features
-        float* dst = P.out + ((size_t)(tile * T + t) * (2 * H / 4) + (dir * KBH + kbo) * 4 + hf) * 128 + (rr & 31) * 4;
-        *(f16x8*)dst = o.t[0];
-        *(f16x8*)(dst + 2 * 128) = o.t[1];
-      }
-    }
-  };
-
-  {
-    const ABase nxt = mk_base(T > 1 ? (dir ? T - 2 : 1) : (dir ? T - 1 : 0));
-    step(std::true_type{}, 0, nxt);
-    cur = nxt;
-  }
-#pragma unroll 1
-  for (int s = 1; s < T; ++s) {
-    const int t = dir ? (T - 1 - s) : s;
-    const ABase nxt = mk_base(s + 1 < T ? (dir ? t - 1 : t + 1) : t);
-    step(std::false_type{}, s, nxt);
-    cur = nxt;
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------
-// lstm_h2o_kernel: lstm_h2_kernel with the VALU work of a step moved into the matrix shadow.
+// lstm_h2o_kernel: grid = lstm_grid(ceil(tiles/(R*WR))), block = 64*NG*WR.  K0 = 4*KQ0, K1 = 4*KQ1, H multiples
+// of 16.  The VALU work of a step runs in the matrix shadow of the next step's input blocks.
 //
-// PMC of lstm_h2_kernel (192->128, profiles/r02b_*): per step a wave spends 15.4 k cycles issuing its
+// PMC of its predecessor with the gates AFTER the matrix phase (lstm_h2_kernel, round 2, in the history;
+// 192->128, profiles/r02b_*): per step a wave spends 15.4 k cycles issuing its
 // 480 MFMAs and another ~8.6 k on ~1700 VALU instructions (gates, the split of h, BatchNorm + split of
 // the output) that run AFTER the matrix phase - the kernel's time is the SUM (matrix pipe 54 % busy).
 // Here the input blocks of step s+1, which do not depend on h_s, are issued while the VALU turns z_s

@@ -32,7 +32,7 @@ SYMBOLS = [
     "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
     "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
     "nrv_window", "nrv_set_precision", "nrv_get_precision", "nrv_predict_reads_raw", "nrv_segment_reads",
-    "nrv_device_count",
+    "nrv_device_count", "nrv_saturated",
 ]
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x2": 2}
@@ -133,6 +133,7 @@ def load_library(path: Optional[str] = None):
     i16p, i32p, rdp = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(_ReadDesc)
     lib.nrv_predict_reads_raw.argtypes = [vp, i16p, C.c_int64, i32p, fp, C.c_int64, rdp, C.c_int, fp, fp, i8p, i8p]
     lib.nrv_segment_reads.argtypes = [vp, i16p, C.c_int64, i32p, C.c_int64, rdp, C.c_int, fp]
+    lib.nrv_saturated.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nrv_set_precision.argtypes = [vp, C.c_int]
     lib.nrv_get_precision.argtypes = [vp]
     if path is None:
@@ -304,15 +305,11 @@ class Reviser:
 
     @staticmethod
     def _fingerprint(a):
-        """Identity + shape + a checksum of the contents: the facade must not serve stale results when a
-        caller refills the same array object between model1.predict and the next read.  Small arrays are
-        hashed whole; above 8 MB one 64-byte line of every KiB (a refill changes practically every line;
-        hashing 190 MB in full would cost more than the prediction it guards)."""
+        """Identity + shape + a checksum of the WHOLE contents: the facade must not serve stale results when a
+        caller edits the same array object in place between model1.predict and model2.predict (xxh3 runs at
+        > 10 GB/s: ~20 ms for the 190 MB of a 64 k-window read, far below the prediction it guards)."""
         v = np.ascontiguousarray(np.asarray(a))
         raw = v.reshape(-1).view(np.uint8)
-        if raw.size > (8 << 20):
-            body = raw[: raw.size // 1024 * 1024].reshape(-1, 1024)[:, :64]
-            raw = np.concatenate([np.ascontiguousarray(body).reshape(-1), raw[raw.size // 1024 * 1024:]])
         try:
             import xxhash
             digest = xxhash.xxh3_64_intdigest(memoryview(raw))
@@ -340,6 +337,33 @@ class Reviser:
         self._check(self._lib.nrv_predict_read_device(self._h, d_sig_ev, d_feat_ev, int(N), d_p1 or None,
                                                       d_p2 or None, d_a1 or None, d_a2 or None))
 
+    def saturated(self):
+        """(pending, reruns) of the f16x2 range guard (include/nanorev.h nrv_saturated): `pending` != 0 means
+        a device-pointer call since the last check left the f16 range of the signal branch and must be
+        repeated in 'f32' precision; `reruns` counts the stages the host entry points already re-ran.
+        Synchronises the handle's stream."""
+        pend, rer = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.nrv_saturated(self._h, C.byref(pend), C.byref(rer)))
+        return int(pend.value), int(rer.value)
+
+    def predict_device_checked(self, d_signal: int, d_read: int, n: int, d_p1: int = 0, d_p2: int = 0,
+                               d_a1: int = 0, d_a2: int = 0, read_mode: bool = False) -> bool:
+        """`predict_device` / `predict_read_device` + the range guard: synchronises, and when the f16x2 signal
+        branch left its range repeats the call on the f32 kernels (same outputs).  Returns True when it did."""
+        call = self.predict_read_device if read_mode else self.predict_device
+        call(d_signal, d_read, n, d_p1, d_p2, d_a1, d_a2)
+        pend, _ = self.saturated()
+        if not pend:
+            return False
+        mode = self.precision
+        self.set_precision("f32")
+        try:
+            call(d_signal, d_read, n, d_p1, d_p2, d_a1, d_a2)
+            self.sync()
+        finally:
+            self.set_precision(mode)
+        return True
+
     def set_batch(self, batch: int):
         self._check(self._lib.nrv_set_batch(self._h, int(batch)))
 
@@ -348,8 +372,8 @@ class Reviser:
         return int(self._lib.nrv_get_batch(self._h))
 
     def set_precision(self, precision: str):
-        """'bf16x3' (default: exact three-term bf16 split on the bf16 matrix pipe, f32-grade results)
-        or 'f32' (plain f32 matrix instructions) for the three large Bi-LSTM layers."""
+        """'f16x2' (default: scaled two-term f16 split, three products per f32-grade product), 'bf16x3' (exact
+        three-term bf16 split, six products) or 'f32' (plain f32 matrix instructions): include/nanorev.h."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self._check(self._lib.nrv_set_precision(self._h, PRECISIONS[precision]))

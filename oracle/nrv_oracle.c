@@ -81,7 +81,7 @@ static void signal_branch(const model_t *m, const float *sig, float *out) {
         int q = p + k - 1;
         if (q >= 0 && q < 50) v += sig[q] * w[0][k * 8 + o];
       }
-      y1[p][o] = v > 0.f ? v : 0.f;
+      y1[p][o] = v < 0.f ? 0.f : v;          /* NaN in, NaN out (as np.maximum) */
     }
     bn(y1[p], 8, w[2], w[3], w[4], w[5]);
   }
@@ -93,7 +93,7 @@ static void signal_branch(const model_t *m, const float *sig, float *out) {
         if (q >= 0 && q < 50)
           for (int c = 0; c < 8; ++c) v += y1[q][c] * w[6][(k * 8 + c) * 8 + o];
       }
-      y2[p][o] = v > 0.f ? v : 0.f;
+      y2[p][o] = v < 0.f ? 0.f : v;
     }
     bn(y2[p], 8, w[8], w[9], w[10], w[11]);
     for (int o = 0; o < 8; ++o) y2[p][o] += sig[p];          /* Add(): broadcast over channels */
@@ -157,7 +157,7 @@ static void dense(const float *x, int K, int N, const float *W, const float *b, 
   }
   for (int j = 0; j < N; ++j) {
     float v = out[j] + b[j];
-    out[j] = relu ? (v > 0.f ? v : 0.f) : v;
+    out[j] = relu ? (v < 0.f ? 0.f : v) : v;
   }
 }
 

@@ -65,3 +65,27 @@ def broken_factory(args, device):
     if device == 1:
         raise RuntimeError("libnanorev_hip: error -3: no HIP device")
     return EchoEngine()
+
+
+class _FailsFirstReadThenDies(EchoEngine):
+    """Fails every call that starts with the first read it ever saw (so the batched call and that read's
+    retry fail, the other read of the batch is revised), then dies hard on its 4th call - the second
+    batch - after giving the queue's feeder thread time to flush the per-file records."""
+    def predict_read(self, sig_ev, feat_ev):
+        import time
+        if self.fail_marker is None:
+            self.fail_marker = feat_ev[0].copy()
+        if self.calls >= 3:
+            time.sleep(1.0)
+            os._exit(134)
+        return super().predict_read(sig_ev, feat_ev)
+
+
+def fails_then_dies_factory(args, device):
+    return _FailsFirstReadThenDies() if device == 1 else EchoEngine()
+
+
+def shared_device_factory(args, device):
+    """The REAL engine for every worker rank, all on device 0 (a 1-GPU box rehearsing the N-worker path)."""
+    from nanoreviser_amd import cli
+    return cli._default_factory(args, 0)

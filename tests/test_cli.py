@@ -10,7 +10,8 @@ import pytest
 from conftest import GOLD, load_read
 from nanoreviser_amd import cli
 from nanoreviser_amd import hoststage as hs
-from echo_engine import EchoEngine, echo_factory, dying_factory, dying_midway_factory, broken_factory
+from echo_engine import (EchoEngine, echo_factory, dying_factory, dying_midway_factory, broken_factory,
+                         fails_then_dies_factory)
 
 FAST5 = os.path.join(GOLD, "fast5")
 
@@ -141,6 +142,32 @@ def test_multi_gpu_worker_that_dies_does_not_hang_the_cli(tmp_path, factory):
     assert len(failed) == 1 and failed[0] in files                     # the dead worker's single read
     for fn in files:                                                   # every read still has an output
         assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + _orig(fn)
+
+
+def test_dead_worker_bookkeeping_uses_reported_files_not_file_existence(tmp_path, monkeypatch):
+    """Worker 1 fails its first read (original bases written, reported failed), revises the second, then dies
+    in its second batch.  The parent must keep the failed read's failed_reads entry, NOT list the revised read,
+    write originals for the two reads that never became final - replacing a stale output an earlier run left
+    under one of those names - and leave no temporary files behind."""
+    import shutil
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    names = ["r0_A", "r1_A", "r2_B", "r3_B", "r4_A", "r5_B", "r6_B", "r7_B"]
+    for n in names:
+        shutil.copy(src[0] if n.endswith("A") else src[1], d / (n + ".fast5"))
+    monkeypatch.setattr(cli, "shard_reads", lambda sizes, world: [[0, 1, 2, 3], [4, 5, 6, 7]])
+    out = str(tmp_path) + "/o/"
+    os.makedirs(out)
+    open(out + "r6_B_out.fasta", "w").write("STALE OUTPUT OF AN EARLIER RUN")
+    rc = cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1", "--batch", "1024", "-e", "bad.txt"],
+                  worker_factory=fails_then_dies_factory, world=2)
+    assert rc == 3
+    assert sorted(open(out + "bad.txt").read().split()) == ["r4_A.fast5", "r6_B.fast5", "r7_B.fast5"]
+    orig = {"A": _orig(os.path.basename(src[0])), "B": _orig(os.path.basename(src[1]))}
+    for n in names:
+        assert open(out + n + "_out.fasta").read() == ">" + n + ".fast5\n" + orig[n[-1]]
+    assert not [f for f in os.listdir(out) if ".tmp" in f]
 
 
 def test_vlen_string_fastq_does_not_discard_the_read(monkeypatch):

@@ -1,0 +1,219 @@
+"""Out-of-range input in every arithmetic mode (MI355X only, -m gpu).
+
+The reference normalises samples as (raw - median) / MAD with no clipping (preprocessing.py:120-131) and runs
+the graph in f32 (nanorevcnn.py:24-37): a spike sample, an open-pore stretch or a tiny MAD has a well-defined
+answer.  The f32 and bf16x3 modes keep f32 buffers; the default f16x2 mode represents the signal branch as
+scaled f16 pairs (|S| < 1023) and must therefore DETECT what it cannot represent and hand back the f32
+kernels' result instead (include/nanorev.h nrv_saturated; nrv_cnn_f16x2.h "RANGE GUARD").  Checked here:
+every mode against the fp64 oracle at 10x / 100x / 1000x the fixture amplitude, spikes inside otherwise clean
+reads (only the affected pipeline stage is re-run, and it is bit-identical to the f32 mode), int16 extremes with
+a tiny MAD through the raw-read entry point, NaN / Inf samples (propagated, not masked), and the
+device-pointer protocol.
+"""
+import numpy as np
+import pytest
+
+from nanoreviser_amd import hoststage as hs
+from parity_policy import check_vs_fp64, f32_floor
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["f16x2", "bf16x3", "f32"]
+
+
+def _fixture_windows(reads, key="ch10_read5252", lo=1000, n=320, T=11):
+    _, _, rt = reads(key)
+    sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, T)
+    return np.ascontiguousarray(sw[lo:lo + n]), np.ascontiguousarray(fw[lo:lo + n])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("amp", [10.0, 100.0, 1000.0])
+def test_amplified_signal_vs_fp64_oracle(reads, species_models, mode, amp):
+    """Whole windows at amp x the fixture amplitude (|x| up to 8.4e3 normalised units): every mode within the
+    parity policy of the fp64 oracle; the f16x2 mode must have noticed (amp >= 100) and re-run the stage."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["ecoli"]
+    sw, fw = _fixture_windows(reads)
+    sig = (sw * np.float32(amp)).astype(np.float32)
+    rv = Reviser(m1, m2, precision=mode)
+    p1, p2, a1, a2 = rv.predict_pair(sig, fw)
+    _, reruns = rv.saturated()
+    rv.close()
+    q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sig, fw, np.float64)
+    nf1, nf2 = f32_floor(m1, m2, sig, fw, q1, q2)
+    # at 1000x the f32 restatements themselves leave BAR/2 on ~1.7 % of these windows (measured on CPU)
+    r1 = check_vs_fp64(p1, a1, q1, nf1, f"{mode} x{amp:g} m1", max_ill=0.04)
+    r2 = check_vs_fp64(p2, a2, q2, nf2, f"{mode} x{amp:g} m2", max_ill=0.04)
+    print(f"RANGE {mode} x{amp:g}: reruns {reruns} m1 {r1} m2 {r2}")
+    if mode == "f16x2" and amp >= 100:
+        assert reruns == 1                       # |S| > 1023: not representable, the stage ran on the f32 kernels
+    if mode != "f16x2":
+        assert reruns == 0
+
+
+def test_fixture_reads_never_trip_the_guard(reads, species_models):
+    """Counter is 0 on every fixture read, both species, window and read mode (the guard costs nothing there)."""
+    from nanoreviser_amd.engine import Reviser
+    for sp in ("ecoli", "human"):
+        rv = Reviser(*species_models[sp], precision="f16x2")
+        for key in reads.keys:
+            _, _, rt = reads(key)
+            rv.predict_read(rt.sig_ev, rt.feat_ev)
+        sw, fw = _fixture_windows(reads, n=5000)
+        rv.predict_pair(sw, fw)
+        assert rv.saturated() == (0, 0), sp
+        rv.close()
+
+
+def test_spike_stage_is_rerun_and_bit_identical_to_f32_mode(reads, species_models):
+    """Three pipeline stages of 4096 windows; a few spike samples (x 2000) in the middle one.  The clean stages
+    keep the f16x2 bits, the spiked stage carries exactly the f32 mode's bits, and all of it meets the policy
+    against fp64."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["human"]
+    _, _, rt = reads("ch13_read2251")
+    sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, 11)
+    sw, fw = np.ascontiguousarray(sw[:3 * 4096]).copy(), np.ascontiguousarray(fw[:3 * 4096])
+    clean = sw.copy()
+    rng = np.random.default_rng(7)
+    hit = 4096 + rng.choice(4096, 40, replace=False)
+    for w in hit:
+        sw[w, rng.integers(11), rng.integers(50)] *= np.float32(2000.0)
+    rv = Reviser(m1, m2, precision="f16x2")
+    base = rv.predict_pair(clean, fw)
+    assert rv.saturated() == (0, 0)
+    got = rv.predict_pair(sw, fw)
+    assert rv.saturated() == (0, 1)                            # exactly the middle stage
+    rv.set_precision("f32")
+    ref32 = rv.predict_pair(sw, fw)
+    rv.close()
+    for g, b, r in zip(got, base, ref32):
+        assert np.array_equal(g[:4096], b[:4096]) and np.array_equal(g[8192:], b[8192:])
+        assert np.array_equal(g[4096:8192], r[4096:8192])
+    # the spiked windows against the fp64 oracle (plus neighbours)
+    idx = np.unique(np.concatenate([hit, hit + 1, np.arange(4096, 4096 + 200)]))
+    s, f = np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx])
+    q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, s, f, np.float64)
+    nf1, nf2 = f32_floor(m1, m2, s, f, q1, q2)
+    check_vs_fp64(got[0][idx], got[2][idx], q1, nf1, "spikes m1", max_ill=0.05)
+    check_vs_fp64(got[1][idx], got[3][idx], q2, nf2, "spikes m2", max_ill=0.05)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_raw_reads_int16_extremes_and_tiny_mad(reads, species_models, mode):
+    """nrv_predict_reads_raw with samples at the int16 limits and a scale (MAD) of 1: normalised samples of
+    +-3e4.  Same windows through the host-cut path of the oracle (segmentation is bit-exact, tested elsewhere)."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["ecoli"]
+    _, rd, rt = reads("ch141_read5436")
+    rr = hs.read_tensors_raw(rd)
+    N = 400
+    starts = rr.starts[:N].copy()
+    raw = rr.raw[: int(starts[-1]) + 60].copy()
+    rng = np.random.default_rng(11)
+    pos = rng.choice(len(raw), 30, replace=False)
+    raw[pos] = rng.choice(np.array([-32768, 32767], np.int16), 30)
+    feat = rr.feat_ev[:N]
+    shift, scale = float(np.median(raw)), 1.0                  # a tiny MAD: every sample is tens of units out
+    rv = Reviser(m1, m2, precision=mode)
+    p1, p2, a1, a2 = rv.predict_reads_raw([raw], [starts], [feat], [shift], [scale])
+    sig_ev = rv.segment_reads([raw], [starts], [shift], [scale])
+    _, reruns = rv.saturated()
+    rv.close()
+    assert np.abs(sig_ev).max() > 3e4
+    assert reruns == (1 if mode == "f16x2" else 0)
+    sw, fw = hs.sliding_windows(sig_ev, feat, 11)
+    sw, fw = np.ascontiguousarray(sw), np.ascontiguousarray(fw)
+    q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float64)
+    nf1, nf2 = f32_floor(m1, m2, sw, fw, q1, q2)
+    check_vs_fp64(p1, a1, q1, nf1, f"{mode} raw extremes m1", max_ill=0.05)
+    check_vs_fp64(p2, a2, q2, nf2, f"{mode} raw extremes m2", max_ill=0.05)
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_nan_and_inf_samples_propagate_like_the_oracle(reads, species_models, bad):
+    """A NaN / Inf sample (or event feature) is not masked into a finite value: exactly the windows the fp64
+    oracle poisons come out NaN with call 0 (NumPy's argmax of NaNs) in every mode, the others are untouched,
+    and the f16x2 result is the f32 kernels' bit for bit (the guard re-ran the stage)."""
+    import warnings
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["ecoli"]
+    sw, fw = _fixture_windows(reads, n=256)
+    sw, fw = sw.copy(), fw.copy()
+    clean = sw.copy()
+    sw[17, 3, 20] = bad
+    sw[200, 10, 49] = bad
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        q1, q2, b1, b2 = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float64)
+    poisoned = ~np.isfinite(q1).all(-1)
+    assert set(np.nonzero(poisoned)[0]) == {17, 200} and (~np.isfinite(q2).all(-1) == poisoned).all()
+    outs = {}
+    for mode in MODES:
+        rv = Reviser(m1, m2, precision=mode)
+        base = rv.predict_pair(clean, fw)
+        outs[mode] = rv.predict_pair(sw, fw)
+        assert rv.saturated()[1] == (1 if mode == "f16x2" else 0)
+        p1, p2, a1, a2 = outs[mode]
+        assert (np.isnan(p1).all(-1) == poisoned).all() and (np.isnan(p2).all(-1) == poisoned).all(), mode
+        assert (a1[poisoned] == b1[poisoned]).all() and (a2[poisoned] == b2[poisoned]).all()
+        if mode != "f16x2":                                    # (there the whole stage moved to the f32 kernels)
+            for x, y in zip(outs[mode], base):
+                assert np.array_equal(x[~poisoned], y[~poisoned])
+        # a NaN event feature takes the other route (lstm1, no guard involved) and must poison its window too
+        f2 = fw.copy()
+        f2[5, 2, 1] = np.nan
+        r1, r2, ra1, _ = rv.predict_pair(clean, f2)
+        assert np.isnan(r1[5]).all() and np.isnan(r2[5]).all() and ra1[5] == 0
+        assert np.isfinite(r1[np.arange(256) != 5]).all()
+        rv.close()
+    for x, y in zip(outs["f16x2"], outs["f32"]):
+        assert np.array_equal(x, y, equal_nan=True)            # the re-run IS the f32 kernels
+
+
+def test_device_pointer_protocol(reads, species_models):
+    """Device-pointer calls are asynchronous: the guard is a pending count read by nrv_saturated, and
+    Reviser.predict_device_checked repeats the call in f32.  Clean input: pending stays 0."""
+    import torch
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["ecoli"]
+    sw, fw = _fixture_windows(reads, n=600)
+    spiked = sw.copy()
+    spiked[300, 5, 25] = 1.0e5
+    rv = Reviser(m1, m2, precision="f16x2", batch=256)
+    f32 = Reviser(m1, m2, precision="f32", batch=256)
+
+    def run(s, checked):
+        d_s, d_f = torch.from_numpy(s).cuda(), torch.from_numpy(fw).cuda()
+        n = len(s)
+        o = (torch.empty(n, 6, device="cuda"), torch.empty(n, 5, device="cuda"),
+             torch.empty(n, dtype=torch.int8, device="cuda"), torch.empty(n, dtype=torch.int8, device="cuda"))
+        torch.cuda.synchronize()
+        ptr = (d_s.data_ptr(), d_f.data_ptr(), n) + tuple(x.data_ptr() for x in o)
+        if checked is None:
+            f32.predict_device(*ptr)
+            f32.sync()
+            return o, None
+        if checked:
+            return o, rv.predict_device_checked(*ptr)
+        rv.predict_device(*ptr)
+        return o, rv.saturated()[0]
+
+    _, pend = run(sw, False)
+    assert pend == 0
+    _, pend = run(spiked, False)
+    assert pend > 0
+    assert rv.saturated()[0] == 0                              # reading clears it
+    o, redone = run(spiked, True)
+    assert redone is True and rv.precision == "f16x2"
+    ref, _ = run(spiked, None)
+    for x, y in zip(o, ref):
+        assert torch.equal(x, y)
+    o, redone = run(sw, True)
+    assert redone is False
+    rv.close(); f32.close()

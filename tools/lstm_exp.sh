@@ -1,12 +1,19 @@
 #!/bin/bash
-# Builds experiment variants of the engine (-DNRV_EXP=<bits>, see nrv_lstm_f16x2.h: parts of lstm_h2o_kernel
-# compiled out; results are WRONG, only the timing means something) into nanoreviser_amd/csrc/exp/.
-# usage: tools/lstm_exp.sh 1 3 7 15 ...     then on the GPU box: scripts/gpu_exp.sh 1 3 7 15
-cd /root/repo/nanoreviser_amd/csrc || exit 1
+# Experiments builds of the engine into nanoreviser_amd/csrc/exp/ (git-ignored; they travel to the GPU box).
+# The product library (__graft_entry__.build) ships only the kernels a documented precision mode reaches;
+# -DNRV_EXPERIMENTS adds the alternative kernels / geometries behind NRV_MFMA16, NRV_HT, NRV_GEO, NRV_PAIR,
+# NRV_SPLIT (DESIGN.md 3 "Environment knobs"), and -DNRV_EXP=<bits> compiles parts of the f16x2 Bi-LSTM kernels
+# out (nrv_lstm_f16x2.h: results are WRONG, only the timing means something).
+#   tools/lstm_exp.sh knobs          -> exp/libnanorev_hip_experiments.so   (tests/test_gpu_knobs.py, NRV_LIB=...)
+#   tools/lstm_exp.sh 1 3 7 15 ...   -> exp/libnanorev_hip_exp<bits>.so     (scripts/gpu_exp.sh 1 3 7 15)
+cd "$(dirname "$0")/../nanoreviser_amd/csrc" || exit 1
 mkdir -p exp
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DNRV_EXPERIMENTS=1 -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000"
 for v in "$@"; do
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DNRV_EXP=$v \
-      -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000 \
-      -o exp/libnanorev_hip_exp$v.so nrv_api.hip > exp/build$v.log 2>&1; echo "exp$v rc=$?" ) &
+  if [ "$v" = knobs ]; then
+    ( /opt/rocm/bin/hipcc $FLAGS -o exp/libnanorev_hip_experiments.so nrv_api.hip > exp/build_knobs.log 2>&1; echo "knobs rc=$?" ) &
+  else
+    ( /opt/rocm/bin/hipcc $FLAGS -DNRV_EXP=$v -o exp/libnanorev_hip_exp$v.so nrv_api.hip > exp/build$v.log 2>&1; echo "exp$v rc=$?" ) &
+  fi
 done
 wait
