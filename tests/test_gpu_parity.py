@@ -161,8 +161,10 @@ def test_config_batch_sizes_C2_C3(reads, species_models, sp, batch):
         assert np.array_equal(x, y) and np.array_equal(x, z)
     c1, ca1 = CO.predict(m1.flat(), 11, 6, sw, fw, threads=8)
     c2, ca2 = CO.predict(m2.flat(), 11, 5, sw, fw, threads=8)
-    assert np.abs(p1 - c1).max() <= 2 * BAR and np.abs(p2 - c2).max() <= 2 * BAR
-    assert (a1 != ca1).sum() + (a2 != ca2).sum() <= 1
+    e1, e2, flips = float(np.abs(p1 - c1).max()), float(np.abs(p2 - c2).max()), int((a1 != ca1).sum() + (a2 != ca2).sum())
+    print(f"MEASURED C2C3 {sp} batch {batch}: max|dp| vs C-f32 m1 {e1:.3e} m2 {e2:.3e}, argmax differences {flips}")
+    assert e1 <= 2 * BAR and e2 <= 2 * BAR
+    assert flips <= 1
 
 
 def test_whole_read_live_oracle_and_read_mode(engines, reads, species_models):
@@ -345,9 +347,12 @@ def test_full_size_properties_device_api(species_models, sp):
     a, b = m1.with_window(T), m2.with_window(T)
     c1, ca1 = CO.predict_read(a.flat(), T, 6, se, fe, threads=8)
     c2, ca2 = CO.predict_read(b.flat(), T, 5, se, fe, threads=8)
-    assert np.abs(p1[lo:lo + cnt].cpu().numpy() - c1).max() <= 2 * BAR
-    assert np.abs(p2[lo:lo + cnt].cpu().numpy() - c2).max() <= 2 * BAR
-    assert (a1[lo:lo + cnt].cpu().numpy() != ca1).sum() + (a2[lo:lo + cnt].cpu().numpy() != ca2).sum() <= 2
+    e1 = float(np.abs(p1[lo:lo + cnt].cpu().numpy() - c1).max())
+    e2 = float(np.abs(p2[lo:lo + cnt].cpu().numpy() - c2).max())
+    flips = int((a1[lo:lo + cnt].cpu().numpy() != ca1).sum() + (a2[lo:lo + cnt].cpu().numpy() != ca2).sum())
+    print(f"MEASURED C5 {sp}: max|dp| vs C-f32 read mode m1 {e1:.3e} m2 {e2:.3e}, argmax differences {flips}")
+    assert e1 <= 2 * BAR and e2 <= 2 * BAR
+    assert flips <= 2
     rv.close()
 
 
@@ -510,6 +515,7 @@ def test_random_shapes_vs_f32_oracle(species_models, precision):
     from oracle import nrv_oracle as O
     rng = np.random.default_rng(20261)
     m1, m2 = species_models["ecoli"]
+    worst = 0.0
     for _ in range(10):
         T = int(rng.integers(1, 33))
         n = int(rng.integers(1, 700))
@@ -521,8 +527,10 @@ def test_random_shapes_vs_f32_oracle(species_models, precision):
         assert rv.precision == precision
         p1, p2, a1, a2 = rv.predict_pair(sig, rd)
         q1, q2, b1, b2 = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float32, recurrent_act=act)
+        worst = max(worst, float(np.abs(p1 - q1).max()), float(np.abs(p2 - q2).max()))
         assert np.abs(p1 - q1).max() <= 2e-4 and np.abs(p2 - q2).max() <= 2e-4, (T, n, batch, act)
         for arr, brr, q in ((a1, b1, q1), (a2, b2, q2)):
             for i in np.nonzero(arr != brr)[0]:
                 assert q[i, brr[i]] - q[i, arr[i]] <= 2e-4, (T, n, batch, act, int(i))
         rv.close()
+    print(f"MEASURED random shapes {precision}: max|dp| vs NumPy-f32 {worst:.3e}")
