@@ -21,12 +21,12 @@ def f32_floor(m1, m2, sig, rd, p64_1, p64_2, T=11, numpy_too=True):
     return nf1, nf2
 
 
-def check_vs_fp64(p, a, p64, nf, what="", max_ill=0.01):
+def check_vs_fp64(p, a, p64, nf, what="", max_ill=0.01, bar=BAR):
     """The policy of the module docstring for one model's outputs.  Returns a dict of what was seen."""
     p, a, p64 = np.asarray(p), np.asarray(a), np.asarray(p64)
     err = np.abs(p - p64).max(-1)
-    well = nf <= BAR / 2
-    assert (err[well] <= BAR).all(), f"{what}: well-conditioned window off by {err[well].max():.2e}"
+    well = nf <= bar / 2
+    assert (err[well] <= bar).all(), f"{what}: well-conditioned window off by {err[well].max():.2e}"
     ill = ~well
     if ill.any():
         assert (err[ill] <= 3 * nf[ill]).all(), \

@@ -131,12 +131,14 @@ def test_whole_reads_vs_both_f32_restatements(engines, reads, species_models, sp
         worst_np = max(worst_np, float(np.abs(p1[sl] - q1).max()), float(np.abs(p2[sl] - q2).max()))
     print(f"PARITY {precision} {sp} whole reads: max|dp| vs C-f32 {worst_c:.2e} ({n_over} of {n_all} windows > 1e-4), "
           f"vs NumPy-f32 {worst_np:.2e}, argmax differences vs C-f32 {n_mis}")
-    # two f32 evaluations differ by at most the sum of their own deviations from fp64 (measured over all
-    # 40 885 windows, profiles/r02a_precision_report.json: C port <= 8.5e-5 / 2.1e-4, engine <= 7.8e-5 /
-    # 1.8e-4 for E. coli / human), and almost never by more than the bar
-    assert n_over <= 0.001 * n_all and worst_np <= 2 * BAR
-    assert worst_c <= (2 * BAR if sp == "ecoli" else 5 * BAR)
-    assert n_mis <= (0 if sp == "ecoli" else 2)
+    # Two f32 evaluations of one graph differ by at most the sum of their own deviations from fp64, so a
+    # handful of windows in 20 000 sit a little over 1e-4 against ANOTHER f32 evaluation (README says so next
+    # to "within 1e-4").  The bars are the maxima measured over the three modes on MI355X (round 3, r03a:
+    # E. coli 1.05e-4, human 1.20e-4 against the C port; 4.2e-5 against NumPy-f32 on the slice) + 10 %; the
+    # kernels are deterministic, so a change here means the arithmetic changed and the numbers are re-measured.
+    assert n_over <= 1 and n_mis == 0
+    assert worst_c <= (1.16e-4 if sp == "ecoli" else 1.32e-4)
+    assert worst_np <= 4.7e-5
 
 
 @pytest.mark.parametrize("sp,batch", [("ecoli", 512), ("human", 4096)])
@@ -163,8 +165,9 @@ def test_config_batch_sizes_C2_C3(reads, species_models, sp, batch):
     c2, ca2 = CO.predict(m2.flat(), 11, 5, sw, fw, threads=8)
     e1, e2, flips = float(np.abs(p1 - c1).max()), float(np.abs(p2 - c2).max()), int((a1 != ca1).sum() + (a2 != ca2).sum())
     print(f"MEASURED C2C3 {sp} batch {batch}: max|dp| vs C-f32 m1 {e1:.3e} m2 {e2:.3e}, argmax differences {flips}")
-    assert e1 <= 2 * BAR and e2 <= 2 * BAR
-    assert flips <= 1
+    # measured maxima over the three modes (r03a): E. coli 2.4e-5, human 9.1e-5; + 10 %
+    assert max(e1, e2) <= (2.7e-5 if sp == "ecoli" else 1.0e-4)
+    assert flips == 0
 
 
 def test_whole_read_live_oracle_and_read_mode(engines, reads, species_models):
@@ -351,8 +354,9 @@ def test_full_size_properties_device_api(species_models, sp):
     e2 = float(np.abs(p2[lo:lo + cnt].cpu().numpy() - c2).max())
     flips = int((a1[lo:lo + cnt].cpu().numpy() != ca1).sum() + (a2[lo:lo + cnt].cpu().numpy() != ca2).sum())
     print(f"MEASURED C5 {sp}: max|dp| vs C-f32 read mode m1 {e1:.3e} m2 {e2:.3e}, argmax differences {flips}")
-    assert e1 <= 2 * BAR and e2 <= 2 * BAR
-    assert flips <= 2
+    # measured maxima over the three modes (r03a): E. coli 1.8e-5, human 3.3e-5; + 10 %
+    assert max(e1, e2) <= (2.0e-5 if sp == "ecoli" else 3.7e-5)
+    assert flips == 0
     rv.close()
 
 
@@ -510,7 +514,7 @@ def test_raw_read_descriptors_are_validated(engines):
 def test_random_shapes_vs_f32_oracle(species_models, precision):
     """Seeded random window lengths (1..32), batch sizes (1..700), launch-group sizes and both
     recurrent activations against the NumPy f32 oracle (scripts/gpu_fuzz.py runs the open-ended
-    version).  Both sides are f32 paths, so the bound is twice the fp32 noise floor."""
+    version).  Both sides are f32 paths: the bound is the measured maximum of their difference + 10 %."""
     from nanoreviser_amd.engine import Reviser
     from oracle import nrv_oracle as O
     rng = np.random.default_rng(20261)
@@ -528,9 +532,10 @@ def test_random_shapes_vs_f32_oracle(species_models, precision):
         p1, p2, a1, a2 = rv.predict_pair(sig, rd)
         q1, q2, b1, b2 = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float32, recurrent_act=act)
         worst = max(worst, float(np.abs(p1 - q1).max()), float(np.abs(p2 - q2).max()))
-        assert np.abs(p1 - q1).max() <= 2e-4 and np.abs(p2 - q2).max() <= 2e-4, (T, n, batch, act)
+        # measured maximum over the three modes (r03a): 2.95e-5; + 10 %
+        assert np.abs(p1 - q1).max() <= 3.3e-5 and np.abs(p2 - q2).max() <= 3.3e-5, (T, n, batch, act)
         for arr, brr, q in ((a1, b1, q1), (a2, b2, q2)):
             for i in np.nonzero(arr != brr)[0]:
-                assert q[i, brr[i]] - q[i, arr[i]] <= 2e-4, (T, n, batch, act, int(i))
+                assert q[i, brr[i]] - q[i, arr[i]] <= 6.6e-5, (T, n, batch, act, int(i))
         rv.close()
     print(f"MEASURED random shapes {precision}: max|dp| vs NumPy-f32 {worst:.3e}")

@@ -43,9 +43,14 @@ def test_amplified_signal_vs_fp64_oracle(reads, species_models, mode, amp):
     rv.close()
     q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sig, fw, np.float64)
     nf1, nf2 = f32_floor(m1, m2, sig, fw, q1, q2)
-    # at 1000x the f32 restatements themselves leave BAR/2 on ~1.7 % of these windows (measured on CPU)
-    r1 = check_vs_fp64(p1, a1, q1, nf1, f"{mode} x{amp:g} m1", max_ill=0.04)
-    r2 = check_vs_fp64(p2, a2, q2, nf2, f"{mode} x{amp:g} m2", max_ill=0.04)
+    # At 1000x (samples of +-8e3, conv features of ~1e5) f32 arithmetic itself is the limit: the 400-term dense
+    # layer cancels to ~0.1 absolute, the restatements leave BAR/2 on ~1.7 % of these windows, and whether a
+    # window looks well-conditioned to the two CPU restatements is partly luck - the f32 MODE, plain f32 matrix
+    # instructions, sits 1.11e-4 from fp64 on such a window (bf16x3 1.37e-4; r03a).  So the bar there is 2e-4,
+    # for every mode alike; 10x and 100x hold the normal 1e-4.  Calls must still be the arbiter's.
+    bar = 2e-4 if amp >= 1000 else 1e-4
+    r1 = check_vs_fp64(p1, a1, q1, nf1, f"{mode} x{amp:g} m1", max_ill=0.04, bar=bar)
+    r2 = check_vs_fp64(p2, a2, q2, nf2, f"{mode} x{amp:g} m2", max_ill=0.04, bar=bar)
     print(f"RANGE {mode} x{amp:g}: reruns {reruns} m1 {r1} m2 {r2}")
     if mode == "f16x2" and amp >= 100:
         assert reruns == 1                       # |S| > 1023: not representable, the stage ran on the f32 kernels
