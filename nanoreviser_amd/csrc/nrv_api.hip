@@ -257,6 +257,48 @@ NRV_HOST_COLD static void pack_lstm_h2s(const Blob& b, int base, int K0, int s0,
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
+// lstm2_t_kernel (nrv_lstm2_t.h): the 32->64 layer's weights as A operands of the transposed product.
+// [dir][kb 3: input, recurrent 0, recurrent 1][tile mt 16][term 2][64 lanes][8 f16]; tile mt = gate g * 4 + unit tile ut;
+// lane l = (m = l & 15, q = l >> 4) holds gate-unit (g, u = 16 ut + m) for the k slots 8 q + j:
+//   input block      feature 8 q + j                                   x 2^(E - s_in)
+//   recurrent block  unit 16 (2 (kb - 1) + (j >> 2)) + 4 q + (j & 3)   x 2^(E - 13)   (the order in which a lane holds h)
+// bias [dir][mt][64 lanes][4] x 2^E in accumulator layout: register r of lane (n, q) is unit 16 ut + 4 q + r.
+NRV_HOST_COLD static void pack_lstm2_t(const Blob& b, int base, int s_in, int E, std::vector<float>& out,
+                                       std::vector<float>& bias) {
+  constexpr int H = 64, Kin = 32;
+  std::vector<uint16_t> w((size_t)2 * 3 * 16 * 2 * 64 * 8, 0);
+  bias.assign((size_t)2 * 16 * 64 * 4, 0.f);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* W = b.t(base + dir * 3 + 0);
+    const float* U = b.t(base + dir * 3 + 1);
+    const float* B = b.t(base + dir * 3 + 2);
+    for (int kb = 0; kb < 3; ++kb)
+      for (int mt = 0; mt < 16; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int g = mt >> 2, ut = mt & 3, u = 16 * ut + (lane & 15), q = lane >> 4;
+            float v;
+            if (kb == 0) {
+              const int f = 8 * q + j;
+              v = f < Kin ? std::ldexp(W[(size_t)f * 4 * H + g * H + u], E - s_in) : 0.f;
+            } else {
+              const int uk = 16 * (2 * (kb - 1) + (j >> 2)) + 4 * q + (j & 3);
+              v = std::ldexp(U[(size_t)uk * 4 * H + g * H + u], E - 13);
+            }
+            const size_t o = ((((size_t)(dir * 3 + kb) * 16 + mt) * 2) * 64 + lane) * 8 + j;
+            split_f16(v, &w[o], &w[o + 64 * 8]);
+          }
+    for (int mt = 0; mt < 16; ++mt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int g = mt >> 2, ut = mt & 3, q = lane >> 4;
+          bias[(((size_t)dir * 16 + mt) * 64 + lane) * 4 + r] = std::ldexp(B[g * H + 16 * ut + 4 * q + r], E);
+        }
+  }
+  out.assign((w.size() + 1) / 2, 0.f);
+  memcpy(out.data(), w.data(), w.size() * 2);
+}
+
 // head_mlp_split_kernel: the three per-timestep dense layers as A operands of the transposed
 // product, 126 fragments [64 lanes][8 bf16] (x3 terms): lane l, element j of a fragment hold
 // W[f][n] with n = 32*mt + (l&31) and f the input feature that the B operand carries in slot
@@ -468,8 +510,11 @@ struct DevModel {
   size_t l_w2g[4], l_b2g[4];        // the same packed two gates per tile (lstm_h2o_kernel GPT = 2)
 #endif
   size_t l_w2s[4], l_b2s[4];        // packed for lstm_h2s_kernel (16x16x32 tiles; unit halves per wave: kUhS)
-  size_t l_w2sf = 0, l_b2sf = 0;    // 256->64 layer with the BatchNorm in front of it folded into weights and bias
-  float descale_f = 1.f;            // (its input is then the raw h x 2^13 of the 192->128 layer)
+  // layers 2, 3 (192->128, 256->64) with the BatchNorm IN FRONT of them folded into their weights and bias:
+  // their BatchNorm'd input segment is then the raw h x 2^13 of the layer before (lstm2_t / lstm_h2s RAW copy-out)
+  size_t l_w2sf[4] = {0, 0, 0, 0}, l_b2sf[4] = {0, 0, 0, 0};
+  float descale_f[4] = {1.f, 1.f, 1.f, 1.f};
+  size_t l2t_w = 0, l2t_b = 0;      // lstm2_t_kernel: transposed fragments / bias image of the 32->64 layer
   float descale[4];
   size_t l1s2, l1h2;
   size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
@@ -652,28 +697,38 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       pack_lstm_h2s(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, kUhS[l]);
       d.l_w2s[l] = put(wp.data(), wp.size());
       d.l_b2s[l] = put(bs.data(), bs.size());
-      if (l == 3) {
-        // BatchNorm(256) between the 192->128 and the 256->64 layer, folded into the latter:
-        //   (h sc + sh) W + b = h (diag(sc) W) + (b + sh W),  so that the former's output is h x 2^13 as it lies in LDS
+      if (l == 1) {
+        pack_lstm2_t(b, lbase[1], sX1, E, wp, bs);
+        d.l2t_w = put(wp.data(), wp.size());
+        d.l2t_b = put(bs.data(), bs.size());
+      }
+      if (l >= 2) {
+        // The BatchNorm in front of this layer - BatchNorm(128) on the first 128 input rows of the 192->128 layer (its
+        // other 64 rows come from the signal branch), BatchNorm(256) on all rows of the 256->64 layer - folded into it:
+        //   (h sc + sh) W + b = h (diag(sc) W) + (b + sh W),
+        // so that the layer before hands over its h x 2^13 as it stands (no BatchNorm, no second split in its epilogue).
+        const int Kf = l == 2 ? 128 : 256;
+        const std::vector<float>& fsc = l == 2 ? sc2 : sc3;
+        const std::vector<float>& fsh = l == 2 ? sh2 : sh3;
         std::vector<float> all(b.p, b.p + b.off.back() + (size_t)C);          // the blob ends with final_out's bias [C]
         for (int dir = 0; dir < 2; ++dir) {
-          float* W = all.data() + b.off[lbase[3] + dir * 3 + 0];
-          float* B = all.data() + b.off[lbase[3] + dir * 3 + 2];
-          const int N4 = 4 * lH[3];
+          float* W = all.data() + b.off[lbase[l] + dir * 3 + 0];
+          float* B = all.data() + b.off[lbase[l] + dir * 3 + 2];
+          const int N4 = 4 * lH[l];
           for (int c = 0; c < N4; ++c) {
             double acc = B[c];
-            for (int k = 0; k < 256; ++k) acc += (double)sh3[k] * (double)W[(size_t)k * N4 + c];
+            for (int k = 0; k < Kf; ++k) acc += (double)fsh[k] * (double)W[(size_t)k * N4 + c];
             B[c] = (float)acc;
           }
-          for (int k = 0; k < 256; ++k)
-            for (int c = 0; c < N4; ++c) W[(size_t)k * N4 + c] *= sc3[k];
+          for (int k = 0; k < Kf; ++k)
+            for (int c = 0; c < N4; ++c) W[(size_t)k * N4 + c] *= fsc[k];
         }
         const Blob bf{all.data(), b.off};
-        const int Ef = plan_exponent(bf, lbase[3], 256, 13, 0, 0, lH[3]);
-        pack_lstm_h2s(bf, lbase[3], 256, 13, 0, 0, lH[3], Ef, wp, bs, kUhS[3]);
-        d.l_w2sf = put(wp.data(), wp.size());
-        d.l_b2sf = put(bs.data(), bs.size());
-        d.descale_f = std::ldexp(1.f, -Ef);
+        const int Ef = plan_exponent(bf, lbase[l], K0[l], 13, K1[l], s1[l], lH[l]);
+        pack_lstm_h2s(bf, lbase[l], K0[l], 13, K1[l], s1[l], lH[l], Ef, wp, bs, kUhS[l]);
+        d.l_w2sf[l] = put(wp.data(), wp.size());
+        d.l_b2sf[l] = put(bs.data(), bs.size());
+        d.descale_f[l] = std::ldexp(1.f, -Ef);
       }
       d.descale[l] = std::ldexp(1.f, -E);
       // the LDS image holds h * 2^13: scale' = scale * 2^(s_out - 13), shift' = shift * 2^s_out
@@ -926,9 +981,10 @@ static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], c
   sa.T = T; sa.n_rows = n;
   for (int m = 0; m < 2; ++m) {
     const DevModel& d = h->dm[m];
-    sa.m[m] = LstmH2ModelParams{d.all + (folded_in ? d.l_w2sf : d.l_w2s[layer]), d.all + (folded_in ? d.l_b2sf : d.l_b2s[layer]),
+    sa.m[m] = LstmH2ModelParams{d.all + (folded_in ? d.l_w2sf[layer] : d.l_w2s[layer]),
+                                d.all + (folded_in ? d.l_b2sf[layer] : d.l_b2s[layer]),
                                 d.all + d.l_s2[layer], d.all + d.l_h2[layer], in0[m], in1[m], out[m],
-                                folded_in ? d.descale_f : d.descale[layer]};
+                                folded_in ? d.descale_f[layer] : d.descale[layer]};
   }
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
@@ -1028,11 +1084,32 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
     }
     const ActView none[2] = {ActView{}, ActView{}};
-    if (h->h2) {
+#ifdef NRV_EXPERIMENTS
+    // NRV_L2T=0: the 32->64 layer on lstm_h2o_kernel (hidden units on the lanes, h through LDS, BatchNorm in its epilogue)
+    static const bool l2t = !(getenv("NRV_L2T") && atoi(getenv("NRV_L2T")) == 0);
+#else
+    constexpr bool l2t = true;
+#endif
+    if (h->h2 && l2t) {
+      // wave-private transposed kernel; hands over h x 2^13 (BatchNorm(128) is in the 192->128 layer's weights)
+      Lstm2TArgs ta;
+      ta.T = T; ta.n_rows = n;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        ta.m[m] = Lstm2TModelParams{d.all + d.l2t_w, d.all + d.l2t_b, h->X1[m], h->X2[m], d.descale[1]};
+      }
+      dim3 grid((n + 63) / 64, 2, 2);
+      if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
+      else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);
+    }
+#ifdef NRV_EXPERIMENTS
+    else if (h->h2) {
       const ActView i0[2] = {win_view(h->X1[0], 8), win_view(h->X1[1], 8)};
       float* const o[2] = {h->X2[0], h->X2[1]};
       launch_lstm_h2<8, 0, 64, 1, 2, false, 8, 2>(h, 1, i0, none, o, T, n, tiles);
-    } else if (h->split & 2) {
+    }
+#endif
+    else if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
       launch_lstm_split<8, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
@@ -1061,11 +1138,11 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // NRV_MFMA16: bit 0 / bit 1 = the 192->128 / 256->64 layer on the 16x16x32 tile (default 3: both, BatchNorm folded)
       static const int m16b = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
       if (m16b != 3) {
-        if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles);
-        else launch_lstm_h2<32, 16, 128, 2, 1, false, 8, 4>(h, 2, i0, i1, o, T, n, tiles);
+        if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles, l2t);
+        else launch_lstm_h2<32, 16, 128, 2, 1, false, 8, 4>(h, 2, i0, i1, o, T, n, tiles);      // (needs NRV_L2T=0)
       } else
 #endif
-      launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles);
+      launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles, l2t);
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);

@@ -34,6 +34,7 @@
 #include "nrv_lstm_bf16x3.h"   // lstm_split_kernel, lstm_pair_kernel
 #include "nrv_lstm_f16x2.h"    // lstm_h2o_kernel (scaled two-term f16 split, NRV_PREC_F16X2)
 #include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (the same on 16x16x32 tiles)
+#include "nrv_lstm2_t.h"       // lstm2_t_kernel (32->64 layer: transposed products, wave-private recurrence)
 #include "nrv_cnn_f16x2.h"     // cnn_h2_kernel (signal branch of the f16x2 mode)
 #include "nrv_head.h"          // head_mlp_kernel, head_mlp_split_kernel, head_final_kernel
 #include "nrv_head_f16x2.h"    // head_h2_kernel (per-timestep MLP + per-window tail, f16x2 mode)
