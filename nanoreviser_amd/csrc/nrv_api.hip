@@ -518,6 +518,9 @@ struct DevModel {
   float descale[4];
   size_t l1s2, l1h2;
   size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
+  size_t cm_w2 = 0, cm_ep = 0;           // cnn_m_kernel: second convolution as an A operand, its epilogue constants
+  size_t cr_w2 = 0, cr_ep = 0, cr_d = 0; // cnn_r_kernel: conv2 in its two-position form, epilogue constants, dense A fragments
+  CnnRConsts cr_k;                       // ... and the first convolution's constants (kernel arguments)
   size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
   HeadH2Scales hsc;
   int C;
@@ -676,6 +679,67 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       d.dsplit_h2 = put(wp.data(), wp.size());
       std::vector<float> db(b.t(33), b.t(33) + 64);
       d.dbias_h2 = put_scaled(db, 16);
+      // cnn_m_kernel (nrv_cnn_m.h): the second convolution x 2^u as the A operand of the transposed product,
+      // [term][lane (co = l & 15, tap = l >> 4)][ci]; c1 is kept x 2^6, so the accumulator holds z x 2^(6+u)
+      const float* w2 = host.data() + d.conv + 48;             // [tap][ci][co]
+      const int u = pow2_room(max_abs(w2, 192));
+      std::vector<uint16_t> frag((size_t)2 * 64 * 8, 0);
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int co = lane & 15, tap = lane >> 4;
+          const float v = (co < 8 && tap < 3) ? std::ldexp(w2[(tap * 8 + j) * 8 + co], u) : 0.f;
+          split_f16(v, &frag[(size_t)lane * 8 + j], &frag[(size_t)512 + lane * 8 + j]);
+        }
+      std::vector<float> ff(frag.size() / 2);
+      memcpy(ff.data(), frag.data(), frag.size() * 2);
+      d.cm_w2 = put(ff.data(), ff.size());
+      float ep[48] = {0};
+      for (int co = 0; co < 8; ++co) {
+        ep[co] = std::ldexp(cv[240 + co], 6 + u);              // bias of the second convolution
+        ep[16 + co] = std::ldexp(cv[248 + co], -6 - u);        // cv[248..]: BatchNorm 2 scale, already x 2^6 -> s2 x 2^-u
+        ep[32 + co] = cv[256 + co];                            // BatchNorm 2 shift x 2^6
+      }
+      d.cm_ep = put(ep, 48);
+      {
+        // cnn_r_kernel (nrv_cnn_r.h).  conv2's A operand gives TWO positions per product: rows 0-7 take tap = k-group,
+        // rows 8-15 tap = k-group - 1 (the B operand's k-groups hold c1 at positions p - 1 .. p + 2).
+        std::vector<uint16_t> fr((size_t)2 * 64 * 8, 0);
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int m = lane & 15, kg = lane >> 4;
+            const int co = m & 7, tap = m < 8 ? kg : kg - 1;
+            const float v = (tap >= 0 && tap < 3) ? std::ldexp(w2[(tap * 8 + j) * 8 + co], u) : 0.f;
+            split_f16(v, &fr[(size_t)lane * 8 + j], &fr[(size_t)512 + lane * 8 + j]);
+          }
+        std::vector<float> f2(fr.size() / 2);
+        memcpy(f2.data(), fr.data(), fr.size() * 2);
+        d.cr_w2 = put(f2.data(), f2.size());
+        float e2[24];
+        for (int co = 0; co < 8; ++co) { e2[co] = ep[co]; e2[8 + co] = ep[16 + co]; e2[16 + co] = ep[32 + co]; }
+        d.cr_ep = put(e2, 24);
+        // dense 400 -> 64 x 2^10 as A fragments in the k order the conv2 result tiles arrive in:
+        // [ks 13][mt 4][term 2][64 lanes][8 f16]; lane (m = l & 15, kg = l >> 4), element j:
+        //   position 4 ks + 2 (j >> 2) + (kg >> 1), channel 4 (kg & 1) + (j & 3), output feature 16 mt + m
+        const float* Wd = b.t(32);
+        std::vector<uint16_t> df((size_t)13 * 4 * 2 * 512, 0);
+        for (int ks = 0; ks < 13; ++ks)
+          for (int mt = 0; mt < 4; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int m = lane & 15, kg = lane >> 4;
+                const int pos = 4 * ks + 2 * (j >> 2) + (kg >> 1), ch = 4 * (kg & 1) + (j & 3);
+                const float v = pos < 50 ? std::ldexp(Wd[(size_t)(pos * 8 + ch) * 64 + 16 * mt + m], 10) : 0.f;
+                const size_t o = ((size_t)((ks * 4 + mt) * 2) * 64 + lane) * 8 + j;
+                split_f16(v, &df[o], &df[o + 512]);
+              }
+        std::vector<float> d2(df.size() / 2);
+        memcpy(d2.data(), df.data(), df.size() * 2);
+        d.cr_d = put(d2.data(), d2.size());
+      }
+      const float* c0 = host.data() + d.conv;                  // unscaled: w1 24, b1 8, s1 8, h1 8
+      memcpy(d.cr_k.w1, c0, 24 * 4);
+      memcpy(d.cr_k.b1, c0 + 24, 8 * 4);
+      for (int o = 0; o < 8; ++o) { d.cr_k.s1[o] = std::ldexp(c0[32 + o], 6); d.cr_k.h1[o] = std::ldexp(c0[40 + o], 6); }
     }
     const int K0[4] = {0, 32, 128, 256}, K1[4] = {0, 0, 64, 0}, s0[4] = {0, sX1, sX2, sX3}, s1[4] = {0, 0, sS, 0};
     const std::vector<float>* osc[4] = {nullptr, &sc2, &sc3, nullptr};
@@ -1027,7 +1091,23 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     const int n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
     // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
     const int blocks = n_tiles < 128 ? n_tiles : 128;
-    if (h->h2) {
+#ifdef NRV_EXPERIMENTS
+    // NRV_CNN=h2: convolutions on the VALU, feature image in LDS (cnn_h2_kernel); m: the 8 -> 8 convolution on the matrix
+    // pipe, feature image in LDS (cnn_m_kernel); default: everything in registers (cnn_r_kernel)
+    static const char* cnnv = getenv("NRV_CNN");
+    const bool cnn_h2v = cnnv && !strcmp(cnnv, "h2"), cnn_mv = cnnv && !strcmp(cnnv, "m");
+    if (h->h2 && cnn_mv) {
+      CnnMArgs a2;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        a2.m[m] = CnnH2ModelParams{d.all + d.conv_h2, d.all + d.dsplit_h2, d.all + d.dbias_h2, h->S[m]};
+        a2.c[m] = CnnMModelParams{d.all + d.cm_w2, d.all + d.cm_ep};
+        static_assert(sizeof(CnnRConsts) == sizeof(CnnMConsts), "same constants");
+        memcpy(&a2.k[m], &d.cr_k, sizeof(CnnMConsts));
+      }
+      a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
+      hipLaunchKernelGGL(cnn_m_kernel, dim3(blocks, 2), dim3(kCnnH2Threads), 0, h->stream, a2);
+    } else if (h->h2 && cnn_h2v) {
       CnnH2Args a2;
       for (int m = 0; m < 2; ++m) {
         const DevModel& d = h->dm[m];
@@ -1035,6 +1115,19 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       }
       a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
       hipLaunchKernelGGL(cnn_h2_kernel, dim3(blocks, 2), dim3(kCnnH2Threads), 0, h->stream, a2);
+    } else
+#endif
+    if (h->h2) {
+      CnnRArgs a2;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.dbias_h2, h->S[m]};
+        a2.k[m] = d.cr_k;
+      }
+      a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
+      // persistent, one workgroup of eight waves per CU and model; a wave takes 16-event units round-robin
+      const int wg = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves;
+      hipLaunchKernelGGL(cnn_r_kernel, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
     } else {
       CnnArgs a;
       for (int m = 0; m < 2; ++m) {

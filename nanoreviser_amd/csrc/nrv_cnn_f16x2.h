@@ -70,6 +70,7 @@ typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) _Float16 lds_f16;
 typedef __attribute__((address_space(3))) f16x8 lds_f16x8;
 
+#ifdef NRV_EXPERIMENTS   // the VALU form of the convolutions: experiments build only (NRV_CNNM=0)
 // conv1+BN -> conv2+BN -> +signal for NP consecutive positions of one event; the 8 channels of a position
 // leave as one scaled hi chunk and one lo chunk of the A-fragment image.  x[] holds samples p0-2 .. p0+NP+1.
 template <int NP>
@@ -155,12 +156,95 @@ __device__ __forceinline__ void conv_positions_h2(const lds_f32* cw, const float
   }
 }
 
+#endif
+
 constexpr int kCnnH2MatWaves = 4, kCnnH2ConvWaves = 8;
 constexpr int kCnnH2Threads = 64 * (kCnnH2MatWaves + kCnnH2ConvWaves);
 constexpr int kCnnH2CH = 33 * 8;                   // f16 per (kb, term, half) chunk: 32 events x 8 + one event of padding
 constexpr int kCnnH2NKB = 26;                      // k-blocks of 16 in the image: 25 real + one of zeros (K = 400 -> 416)
 constexpr int kCnnH2IMG = kCnnH2NKB * 4 * kCnnH2CH;  // f16 per image
 
+// The dense role of the signal branch (waves 0-3 of cnn_h2_kernel / cnn_m_kernel): wave ct owns output columns
+// 16 ct .. + 15 of the 400 -> 64 layer, all 13 k-steps of 32, both row halves; its B fragments (26 KB) stay in
+// registers for the whole launch; tile i - 1's image is multiplied while tile i is being built (one barrier per
+// tile, matched by the conv role).  Range guard: see the header comment above.
+__device__ __forceinline__ void cnn_dense_role(const CnnH2ModelParams& P, lds_f16* const img, const int nloc, const int G,
+                                               const int wave, const int lane, unsigned* sat) {
+  constexpr int CH = kCnnH2CH, IMG = kCnnH2IMG;
+  // wave ct: output columns 16 ct .. +15, all 13 k-steps of 32, both row halves; its B fragments (26 KB)
+  // stay in registers for the whole launch
+  const int ct = wave;
+  const int n16 = lane & 15, kg = lane >> 4;
+  constexpr int NKS = 13;
+  f16x8 bw[NKS][2];
+#pragma unroll
+  for (int k = 0; k < NKS; ++k)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+      bw[k][tm] = *(const f16x8*)((const char*)P.dsplit + ((size_t)((k * 4 + ct) * 2 + tm) * 64 + lane) * 16);
+  const float bias = P.dbias[ct * 16 + n16];
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};           // lo*hi, hi*lo, hi*hi
+  bool bad = false;                              // range guard: an output that is not |v| <= f16 max (NaN included)
+  __syncthreads();                               // tile 0 is being convolved
+  for (int i = 1; i <= nloc; ++i) {
+#if !(NRV_EXP & 2048)                               // timing experiment: no dense layer at all
+    {
+      const lds_f16* im = img + ((i - 1) & 1) * IMG;
+      // A fragment of k-step ks, row half rh: lane (row n16, k-group kg) reads k-block 2 ks + (kg >> 1),
+      // half kg & 1, event 16 rh + n16
+      const lds_f16* ap = im + ((kg >> 1) * 4 + (kg & 1)) * CH + n16 * 8;
+      f32x4 acc[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
+      f16x8 at[2][2][2];                                             // A: ring of two k-steps [slot][row half][term]
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        at[0][rh][0] = *(const lds_f16x8*)(ap + rh * 16 * 8);
+        at[0][rh][1] = *(const lds_f16x8*)(ap + rh * 16 * 8 + 2 * CH);
+      }
+#pragma unroll
+      for (int k = 0; k < NKS; ++k) {
+        if (k + 1 < NKS) {
+#pragma unroll
+          for (int rh = 0; rh < 2; ++rh) {
+            at[(k + 1) & 1][rh][0] = *(const lds_f16x8*)(ap + (k + 1) * 8 * CH + rh * 16 * 8);
+            at[(k + 1) & 1][rh][1] = *(const lds_f16x8*)(ap + (k + 1) * 8 * CH + rh * 16 * 8 + 2 * CH);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+            acc[rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[k & 1][rh][PA[pr]], bw[k][PB[pr]], acc[rh], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // epilogue: S x 2^6 as f16 split planes
+      float* dst = P.out + (size_t)(blockIdx.x + (i - 1) * G) * 16 * 128;
+      const int u = ct * 16 + n16;                // output feature of this lane
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = rh * 16 + 4 * kg + q;
+          const float v = acc[rh][q] * kDenseDescale;
+          bad |= !(__builtin_fabsf(v) <= 65504.f);
+          const _Float16 hi = (_Float16)v;
+          const _Float16 lo = (_Float16)(v - (float)hi);
+          _Float16* d16 = (_Float16*)(dst + ((u >> 4) * 4 + ((u >> 3) & 1)) * 128 + row * 4) + (u & 7);
+#if !(NRV_EXP & 8192)                               // timing experiment: no epilogue stores
+          d16[0] = hi;
+          d16[2 * 128 * 2] = lo;
+#else
+          if (v == 1.2345f) { d16[0] = hi; d16[2 * 128 * 2] = lo; }
+#endif
+        }
+    }
+#endif
+    __syncthreads();
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(sat, 1u);
+}
+
+#ifdef NRV_EXPERIMENTS
 __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args args) {
   constexpr int CH = kCnnH2CH, IMG = kCnnH2IMG;
   __shared__ __attribute__((aligned(16))) _Float16 img_s[2 * IMG];
@@ -228,73 +312,10 @@ __global__ void __launch_bounds__(kCnnH2Threads) cnn_h2_kernel(const CnnH2Args a
     else tile_loop(std::integral_constant<int, 3>{});
     __syncthreads();                               // the matrix role's last tile
   } else {
-    // ================================ MATRIX role ============================================
-    // wave ct: output columns 16 ct .. +15, all 13 k-steps of 32, both row halves; its B fragments (26 KB)
-    // stay in registers for the whole launch
-    const int ct = wave;
-    const int n16 = lane & 15, kg = lane >> 4;
-    constexpr int NKS = 13;
-    f16x8 bw[NKS][2];
-#pragma unroll
-    for (int k = 0; k < NKS; ++k)
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-        bw[k][tm] = *(const f16x8*)((const char*)P.dsplit + ((size_t)((k * 4 + ct) * 2 + tm) * 64 + lane) * 16);
-    const float bias = P.dbias[ct * 16 + n16];
-    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};           // lo*hi, hi*lo, hi*hi
-    bool bad = false;                              // range guard: an output that is not |v| <= f16 max (NaN included)
-    __syncthreads();                               // tile 0 is being convolved
-    for (int i = 1; i <= nloc; ++i) {
-      {
-        const lds_f16* im = img + ((i - 1) & 1) * IMG;
-        // A fragment of k-step ks, row half rh: lane (row n16, k-group kg) reads k-block 2 ks + (kg >> 1),
-        // half kg & 1, event 16 rh + n16
-        const lds_f16* ap = im + ((kg >> 1) * 4 + (kg & 1)) * CH + n16 * 8;
-        f32x4 acc[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
-        f16x8 at[2][2][2];                                             // A: ring of two k-steps [slot][row half][term]
-#pragma unroll
-        for (int rh = 0; rh < 2; ++rh) {
-          at[0][rh][0] = *(const lds_f16x8*)(ap + rh * 16 * 8);
-          at[0][rh][1] = *(const lds_f16x8*)(ap + rh * 16 * 8 + 2 * CH);
-        }
-#pragma unroll
-        for (int k = 0; k < NKS; ++k) {
-          if (k + 1 < NKS) {
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-              at[(k + 1) & 1][rh][0] = *(const lds_f16x8*)(ap + (k + 1) * 8 * CH + rh * 16 * 8);
-              at[(k + 1) & 1][rh][1] = *(const lds_f16x8*)(ap + (k + 1) * 8 * CH + rh * 16 * 8 + 2 * CH);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
-              acc[rh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[k & 1][rh][PA[pr]], bw[k][PB[pr]], acc[rh], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // epilogue: S x 2^6 as f16 split planes
-        float* dst = P.out + (size_t)(blockIdx.x + (i - 1) * G) * 16 * 128;
-        const int u = ct * 16 + n16;                // output feature of this lane
-#pragma unroll
-        for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = rh * 16 + 4 * kg + q;
-            const float v = acc[rh][q] * kDenseDescale;
-            bad |= !(__builtin_fabsf(v) <= 65504.f);
-            const _Float16 hi = (_Float16)v;
-            const _Float16 lo = (_Float16)(v - (float)hi);
-            _Float16* d16 = (_Float16*)(dst + ((u >> 4) * 4 + ((u >> 3) & 1)) * 128 + row * 4) + (u & 7);
-            d16[0] = hi;
-            d16[2 * 128 * 2] = lo;
-          }
-      }
-      __syncthreads();
-    }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(args.sat, 1u);
+    cnn_dense_role(P, img, nloc, G, wave, lane, args.sat);
   }
 }
+
+#endif
 
 }  // namespace nrv

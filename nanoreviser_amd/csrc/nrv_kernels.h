@@ -35,7 +35,9 @@
 #include "nrv_lstm_f16x2.h"    // lstm_h2o_kernel (scaled two-term f16 split, NRV_PREC_F16X2)
 #include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (the same on 16x16x32 tiles)
 #include "nrv_lstm2_t.h"       // lstm2_t_kernel (32->64 layer: transposed products, wave-private recurrence)
-#include "nrv_cnn_f16x2.h"     // cnn_h2_kernel (signal branch of the f16x2 mode)
+#include "nrv_cnn_f16x2.h"     // cnn_h2_kernel (signal branch of the f16x2 mode, convolutions on the VALU), cnn_dense_role
+#include "nrv_cnn_m.h"         // cnn_m_kernel (the same with the 8 -> 8 convolution on the matrix pipe)
+#include "nrv_cnn_r.h"         // cnn_r_kernel (signal branch of the f16x2 mode: conv1 -> conv2 -> dense in registers)
 #include "nrv_head.h"          // head_mlp_kernel, head_mlp_split_kernel, head_final_kernel
 #include "nrv_head_f16x2.h"    // head_h2_kernel (per-timestep MLP + per-window tail, f16x2 mode)
 #include "nrv_segment.h"       // segment_kernel
