@@ -52,11 +52,16 @@ struct CnnRArgs {
   unsigned* sat;           // range guard counter
 };
 
+#ifndef NRV_CNNR_PK
+#define NRV_CNNR_PK 0
+#endif
+#ifndef NRV_CNNR_SGB
+#define NRV_CNNR_SGB 1
+#endif
 #ifndef NRV_CNNR_WAVES
 #define NRV_CNNR_WAVES 8
 #endif
 constexpr int kCnnRWaves = NRV_CNNR_WAVES, kCnnRThreads = 64 * kCnnRWaves;
-constexpr int kCnnRXs = 52;                             // samples per event in the wave-private image: index p + 1, zero halo
 constexpr float kCnnRImgScale = 64.0f;                  // 2^6
 constexpr float kCnnRDenseDescale = 1.0f / 1024.0f;     // 2^-10
 
@@ -65,10 +70,15 @@ typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f32r;
 
+// Wave-private ring of conv1 results: 11 position slots (9 are live at any time), one all-zero slot (the second
+// convolution's zero padding) and one write-only slot for positions past the window (so that the conv1 code has
+// no branch and stays in one basic block with the MFMAs it is interleaved with); each [term 2][event 16][8 f16] = 512 B.
+constexpr int kCnnRRing = 11, kCnnRSlot = 2 * 16 * 8, kCnnRC1Wave = (kCnnRRing + 2) * kCnnRSlot;   // f16
+
 __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args) {
   constexpr int NKS = 13;
-  __shared__ __attribute__((aligned(16))) float wd_s[NKS * 4 * 2 * 256];          // 104 KiB
-  __shared__ __attribute__((aligned(16))) float xr_s[kCnnRWaves * 16 * kCnnRXs];  // 26 KiB
+  __shared__ __attribute__((aligned(16))) float wd_s[NKS * 4 * 2 * 256];            // 104 KiB
+  __shared__ __attribute__((aligned(16))) _Float16 c1_s[kCnnRWaves * kCnnRC1Wave];  // 6.5 KiB per wave
   const CnnRModelParams& P = args.m[blockIdx.y];
   const CnnRConsts& K = args.k[blockIdx.y];
   const int T = args.T;
@@ -86,11 +96,13 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
       for (int j = 0; j < 8; ++j)
         if (base + j * kCnnRThreads + threadIdx.x < NKS * 8 * 64) ((f32x4*)wd_s)[base + j * kCnnRThreads + threadIdx.x] = v[j];
     }
-    for (int i = threadIdx.x; i < kCnnRWaves * 16 * kCnnRXs; i += kCnnRThreads) xr_s[i] = 0.f;   // the halos stay zero
+    for (int i = threadIdx.x; i < kCnnRWaves * kCnnRC1Wave; i += kCnnRThreads) c1_s[i] = (_Float16)0.f;   // incl. the zero slots
   }
   __syncthreads();                                   // the only barrier: from here on the waves are independent
 
-  lds_f32r* const xr = (lds_f32r*)xr_s + wave * 16 * kCnnRXs;
+  typedef __attribute__((address_space(3))) _Float16 lds_h;
+  typedef __attribute__((address_space(3))) f16x8 lds_h8;
+  lds_h* const c1 = (lds_h*)c1_s + wave * kCnnRC1Wave;
   const f16x8 a2_hi = *(const f16x8*)((const char*)P.w2frag + lane * 16);
   const f16x8 a2_lo = *(const f16x8*)((const char*)P.w2frag + 1024 + lane * 16);
   const int c0 = 4 * (q & 1);                        // this lane's conv2 output channels c0 .. c0 + 3
@@ -102,84 +114,185 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
   for (int mt = 0; mt < 4; ++mt) dbias[mt] = *(const f32x4*)(P.dbias + 16 * mt + 4 * q);
   const float* wd = wd_s + lane * 4;
   bool bad = false;
+  // The first convolution's 48 constants, in VECTOR registers for the whole launch.  As kernel arguments (SGPRs) they
+  // do not fit beside the loop's other scalars: hipcc re-loaded them with three s_load_dwordx16 in EVERY k-step, and the
+  // conv1 code waited for the scalar cache each time.  The opaque copy keeps the values from being re-materialised.
+  float w1v[24], b1v[8], s1v[8], h1v[8];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) { w1v[i] = K.w1[i]; asm volatile("" : "+v"(w1v[i])); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    b1v[i] = K.b1[i]; s1v[i] = K.s1[i]; h1v[i] = K.h1[i];
+    asm volatile("" : "+v"(b1v[i]), "+v"(s1v[i]), "+v"(h1v[i]));
+  }
+  // ring slot of position pos: pos % 12 inside the window, the zero slot outside; this lane's event row inside the slot
+  auto slot_of = [&](int pos) __attribute__((always_inline)) {
+    return ((pos >= 0 && pos < kSig) ? (pos % kCnnRRing) : kCnnRRing) * kCnnRSlot + n * 8;
+  };
 
-  // units of 16 events: unit u = 2 * tile + sub, dealt round-robin over all waves of the launch's workgroups
+#if NRV_EXP & 1                                      // timing experiments (results wrong): 1 no units at all
+  const int n_units = 0;
+#else
   const int n_units = 2 * args.n_tiles;
+#endif
+  // units of 16 events: unit u = 2 * tile + sub, dealt round-robin over all waves of the launch's workgroups
+  // conv1 + BatchNorm of position pos (this lane's event) from its three samples -> ring slot, both terms.
+  // (NRV_CNNR_PK=1 writes the channel pairs as packed f32 math, v_pk_fma_f32: measured SLOWER, 73 vs 67 us.)
+  auto conv1_store = [&](int pos, float xm, float xc, float xp) __attribute__((always_inline)) {
+    {
+#if NRV_CNNR_PK
+      const f32x2r xm2 = {xm, xm}, xc2 = {xc, xc}, xp2 = {xp, xp};
+      f16x8 hi, lo;
+#pragma unroll
+      for (int o = 0; o < 8; o += 2) {
+        f32x2r tt = {b1v[o], b1v[o + 1]};
+        tt = __builtin_elementwise_fma(xm2, f32x2r{w1v[0 * 8 + o], w1v[0 * 8 + o + 1]}, tt);
+        tt = __builtin_elementwise_fma(xc2, f32x2r{w1v[1 * 8 + o], w1v[1 * 8 + o + 1]}, tt);
+        tt = __builtin_elementwise_fma(xp2, f32x2r{w1v[2 * 8 + o], w1v[2 * 8 + o + 1]}, tt);
+        tt = __builtin_elementwise_max(tt, f32x2r{0.f, 0.f});
+        tt = __builtin_elementwise_fma(tt, f32x2r{s1v[o], s1v[o + 1]}, f32x2r{h1v[o], h1v[o + 1]});
+        const f16x2r hp = __builtin_convertvector(tt, f16x2r);
+        hi[o] = hp[0]; hi[o + 1] = hp[1];
+        const f16x2r lp = __builtin_convertvector(tt - __builtin_convertvector(hp, f32x2r), f16x2r);
+        lo[o] = lp[0]; lo[o + 1] = lp[1];
+      }
+#else
+      float c[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float tt = b1v[o];
+        tt = __builtin_fmaf(xm, w1v[0 * 8 + o], tt);
+        tt = __builtin_fmaf(xc, w1v[1 * 8 + o], tt);
+        tt = __builtin_fmaf(xp, w1v[2 * 8 + o], tt);
+        tt = __builtin_fmaxf(tt, 0.f);
+        c[o] = __builtin_fmaf(tt, s1v[o], h1v[o]);
+      }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int o = 0; o < 8; o += 2) {
+        const f16x2r hp = __builtin_convertvector(f32x2r{c[o], c[o + 1]}, f16x2r);
+        hi[o] = hp[0]; hi[o + 1] = hp[1];
+        const f16x2r lp = __builtin_convertvector(f32x2r{c[o] - (float)hp[0], c[o + 1] - (float)hp[1]}, f16x2r);
+        lo[o] = lp[0]; lo[o + 1] = lp[1];
+      }
+#endif
+      lds_h* d = c1 + (pos < kSig ? pos % kCnnRRing : kCnnRRing + 1) * kCnnRSlot + n * 8;
+      *(lds_h8*)d = hi;
+      *(lds_h8*)(d + 16 * 8) = lo;
+    }
+  };
+
   for (int u = blockIdx.x * kCnnRWaves + wave; u < n_units; u += gridDim.x * kCnnRWaves) {
     const int b = u >> 1, sub = u & 1;
     const int wt = b / T, t = b % T;
-    // ---- the unit's samples -> wave-private image xr[event][p + 1]
+    const int row = 16 * sub + n;
+    const bool rok = wt * 32 + row < args.n_rows;
+    // this lane's event: samples straight from memory (200 B per event, L1-resident for the length of the unit)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(args.signal + ((size_t)wt * 32 * T + t) * kSig, 0xffffffffu);
+    const unsigned xoff = rok ? (unsigned)(row * T * kSig) * 4u : 0u;
+    auto ldx = [&](int pos) __attribute__((always_inline)) {         // x[pos], zero outside the window / past the rows
+      const bool ok = rok && pos >= 0 && pos < kSig;
+      const float v = buf_load4(rs, xoff + (ok ? (unsigned)pos * 4u : 0u), 0);
+      return ok ? v : 0.f;
+    };
+    // prologue: conv1 of positions 0..3 (set 0), the samples of set 1 and the residual samples of k-step 0 in flight.
+    // (Fetching the NEXT unit's first samples in this unit's last two k-steps, which load nothing useful, was built
+    // and measured: 73 us instead of 65.)
+    float xa[3], xres[2];
     {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(args.signal + ((size_t)wt * 32 * T + t) * kSig, 0xffffffffu);
-      float v[13];
+      const float x0 = ldx(q - 1), x1 = ldx(q), x2 = ldx(q + 1);
 #pragma unroll
-      for (int it = 0; it < 13; ++it) {
-        const int idx = lane + 64 * it;                // 0 .. 831; 800 real
-        const int ev = idx / kSig, p = idx - ev * kSig;
-        const int row = 16 * sub + ev;
-        const bool ok = idx < 16 * kSig && wt * 32 + row < args.n_rows;
-        const float x = buf_load4(rs, ok ? (unsigned)((row * T * kSig + p) * 4) : 0u, 0);
-        v[it] = ok ? x : 0.f;
-      }
+      for (int k = 0; k < 3; ++k) xa[k] = ldx(4 + q - 1 + k);
 #pragma unroll
-      for (int it = 0; it < 13; ++it) {
-        const int idx = lane + 64 * it;
-        const int ev = idx / kSig, p = idx - ev * kSig;
-        if (idx < 16 * kSig) xr[ev * kCnnRXs + p + 1] = v[it];
-      }
+      for (int pi = 0; pi < 2; ++pi) xres[pi] = ldx(2 * pi + (q >> 1));
+      conv1_store(q, x0, x1, x2);
     }
-    wave_lds_fence();
-    const lds_f32r* const xe = xr + n * kCnnRXs;       // this lane's event
 
     f32x4 S[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) S[mt] = dbias[mt];
 
-#pragma unroll 1
-    for (int ks = 0; ks < NKS; ++ks) {
-      // dense weights of this k-step: requested now, used after the two conv pairs
-      f32x4 wf[4][2];
+    f16x8 fb_hi, fb_lo;                                // B fragment of a dense k-step (carried into the next iteration)
+    f32x4 wf[4][2];                                    // ... and that k-step's weights
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fb_hi[j] = (_Float16)0.f; fb_lo[j] = (_Float16)0.f; }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { wf[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; wf[mt][1] = wf[mt][0]; }
+    auto dense = [&]() __attribute__((always_inline)) { // 4 output tiles x (hi*hi, hi*lo, lo*hi)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
+        const f16x8 w_hi = __builtin_bit_cast(f16x8, wf[mt][0]), w_lo = __builtin_bit_cast(f16x8, wf[mt][1]);
+#if NRV_EXP & 4                                      // 4: no dense MFMAs
+        S[mt][0] += (float)w_hi[0] + (float)w_lo[0] + (float)fb_hi[mt] + (float)fb_lo[mt];
+#else
+        S[mt] = mfma16_f16(w_hi, fb_hi, S[mt]);
+        S[mt] = mfma16_f16(w_hi, fb_lo, S[mt]);
+        S[mt] = mfma16_f16(w_lo, fb_hi, S[mt]);
+#endif
+      }
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < ((NRV_EXP & 2) ? 1 : NKS); ++ks) {
+      // The dense products of k-step ks - 1 go FIRST: they depend on nothing computed in this iteration, and the
+      // conv1 arithmetic below is interleaved with them (one MFMA, three vector instructions, ...): measured with
+      // parts compiled out, the MFMAs at the END of a k-step added their full pipe time to the launch (12.6 us).
+      dense();                                         // (k-step "-1": zero fragments)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {                 // this k-step's dense weights (used at the top of the next iteration)
         wf[mt][1] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2 + 1) * 256);
         wf[mt][0] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2) * 256);
       }
-      f16x8 fb_hi, fb_lo;                              // B fragment of the dense k-step
+      // conv1 of the NEXT set (positions 4 ks + 4 .. + 7; pair B below needs its first position), samples one step ahead
+      const float xr0 = xres[0] * kCnnRImgScale, xr1 = xres[1] * kCnnRImgScale;
+      {
+        const float x0 = xa[0], x1 = xa[1], x2 = xa[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xa[k] = ldx(4 * (ks + 2) + q - 1 + k);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) xres[pi] = ldx(4 * (ks + 1) + 2 * pi + (q >> 1));
+#if !(NRV_EXP & 16)                                  // 16: no conv1 in the loop
+        conv1_store(4 * (ks + 1) + q, x0, x1, x2);
+#else
+        if (x0 + x1 + x2 == 1.2345f) conv1_store(4 * (ks + 1) + q, x0, x1, x2);
+#endif
+      }
+#if NRV_CNNR_SGB
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
+      }
+#endif
+      wave_lds_fence();                                // other quarters' conv1 results -> this lane's fragment reads
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const int p = 4 * ks + 2 * pi;                 // this triple gives positions p, p + 1
-        // ---- conv1 + BatchNorm at position pp = p + q - 1 of this lane's event (zero outside the window)
-        const int pp = p + q - 1;
-        const bool inside = pp >= 0 && pp < kSig;
-        const int rp = pp < 0 ? 0 : (pp > kSig - 1 ? kSig - 1 : pp);
-        const float xm = xe[rp], xc = xe[rp + 1], xp = xe[rp + 2];      // x[rp - 1], x[rp], x[rp + 1]
-        float c[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          float tt = K.b1[o];
-          tt = __builtin_fmaf(xm, K.w1[0 * 8 + o], tt);
-          tt = __builtin_fmaf(xc, K.w1[1 * 8 + o], tt);
-          tt = __builtin_fmaf(xp, K.w1[2 * 8 + o], tt);
-          tt = __builtin_fmaxf(tt, 0.f);
-          tt = __builtin_fmaf(tt, K.s1[o], K.h1[o]);
-          c[o] = inside ? tt : 0.f;
-        }
-        f16x8 b_hi, b_lo;
-#pragma unroll
-        for (int o = 0; o < 8; o += 2) {
-          const f16x2r hp = __builtin_convertvector(f32x2r{c[o], c[o + 1]}, f16x2r);
-          b_hi[o] = hp[0]; b_hi[o + 1] = hp[1];
-          const f16x2r lp = __builtin_convertvector(f32x2r{c[o] - (float)hp[0], c[o + 1] - (float)hp[1]}, f16x2r);
-          b_lo[o] = lp[0]; b_lo[o + 1] = lp[1];
-        }
+        const lds_h* src = c1 + slot_of(p + q - 1);    // B operand: k-group q = tap q, i.e. c1 at position p + q - 1
+        const f16x8 b_lo = *(const lds_h8*)(src + 16 * 8);
+        const f16x8 b_hi = *(const lds_h8*)src;
         // ---- conv2: positions p (rows 0-7) and p + 1 (rows 8-15) of 16 events
         f32x4 acc = binit;
+#if NRV_EXP & 8                                      // 8: no conv2 MFMAs
+        acc[0] += (float)b_hi[0] + (float)b_lo[1];
+#else
         acc = mfma16_f16(a2_hi, b_hi, acc);
         acc = mfma16_f16(a2_hi, b_lo, acc);
         acc = mfma16_f16(a2_lo, b_hi, acc);
+#endif
         // ---- bias is in, ReLU, BatchNorm, + sample (x 2^6), split: elements 4 pi .. 4 pi + 3 of the dense B fragment
-        const int P2 = p + (q >> 1);                   // this lane's position (<= 51; 50, 51 meet zero weights)
-        const float xs = xe[(P2 < kSig ? P2 : kSig - 1) + 1] * kCnnRImgScale;
+        // (this lane: position p + (q >> 1); positions 50, 51 of the last k-step meet zero weights)
+        const float xs = pi ? xr1 : xr0;
+#if NRV_CNNR_PK
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          f32x2r v = __builtin_elementwise_max(f32x2r{acc[r], acc[r + 1]}, f32x2r{0.f, 0.f});
+          v = __builtin_elementwise_fma(v, f32x2r{k1[r], k1[r + 1]}, f32x2r{k2[r], k2[r + 1]} + f32x2r{xs, xs});
+          const f16x2r hp = __builtin_convertvector(v, f16x2r);
+          fb_hi[4 * pi + r] = hp[0]; fb_hi[4 * pi + r + 1] = hp[1];
+          const f16x2r lp = __builtin_convertvector(v - __builtin_convertvector(hp, f32x2r), f16x2r);
+          fb_lo[4 * pi + r] = lp[0]; fb_lo[4 * pi + r + 1] = lp[1];
+        }
+#else
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(__builtin_fmaxf(acc[r], 0.f), k1[r], k2[r] + xs);
@@ -190,16 +303,10 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
           const f16x2r lp = __builtin_convertvector(f32x2r{v[r] - (float)hp[0], v[r + 1] - (float)hp[1]}, f16x2r);
           fb_lo[4 * pi + r] = lp[0]; fb_lo[4 * pi + r + 1] = lp[1];
         }
-      }
-      // ---- dense k-step: 4 output tiles x (hi*hi, hi*lo, lo*hi)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const f16x8 w_hi = __builtin_bit_cast(f16x8, wf[mt][0]), w_lo = __builtin_bit_cast(f16x8, wf[mt][1]);
-        S[mt] = mfma16_f16(w_hi, fb_hi, S[mt]);
-        S[mt] = mfma16_f16(w_hi, fb_lo, S[mt]);
-        S[mt] = mfma16_f16(w_lo, fb_hi, S[mt]);
+#endif
       }
     }
+    dense();                                           // the last k-step's products
     // ---- S x 2^6 as f16 split planes: output features 16 mt + 4 q .. + 3 of event n = 8 bytes per term
     float* dst = P.out + (size_t)b * 16 * 128 + (q >> 1) * 128 + (16 * sub + n) * 4 + (q & 1) * 2;
 #pragma unroll
@@ -217,7 +324,7 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
       *(f16x4r*)(dst + (4 * mt) * 128) = f16x4r{h01[0], h01[1], h23[0], h23[1]};
       *(f16x4r*)(dst + (4 * mt + 2) * 128) = f16x4r{l01[0], l01[1], l23[0], l23[1]};
     }
-    wave_lds_fence();                                  // the next unit overwrites the sample image
+    wave_lds_fence();                                  // the next unit overwrites the ring
   }
   if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(args.sat, 1u);
 }
