@@ -40,7 +40,7 @@ print("RESULT " + json.dumps(out))
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="experiments library not built (tools/lstm_exp.sh knobs)")
 @pytest.mark.parametrize("knob,prec", [("NRV_L2T=0;NRV_MFMA16=0", "f16x2"), ("NRV_L2T=0;NRV_MFMA16=0;NRV_HT=0", "f16x2"),
-                                       ("NRV_MFMA16=1", "f16x2"), ("NRV_MFMA16=2", "f16x2"), ("NRV_L2T=0", "f16x2"),
+                                       ("NRV_MFMA16=1", "f16x2"), ("NRV_L2T=0;NRV_MFMA16=2", "f16x2"), ("NRV_L2T=0", "f16x2"),
                                        ("NRV_CNN=h2", "f16x2"), ("NRV_CNN=m", "f16x2"),
                                        ("NRV_PAIR=0", "bf16x3"), ("NRV_GEO=-1,0,1,0", "f32")])
 def test_alternative_kernels_match_the_goldens(knob, prec):

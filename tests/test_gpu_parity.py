@@ -133,11 +133,11 @@ def test_whole_reads_vs_both_f32_restatements(engines, reads, species_models, sp
           f"vs NumPy-f32 {worst_np:.2e}, argmax differences vs C-f32 {n_mis}")
     # Two f32 evaluations of one graph differ by at most the sum of their own deviations from fp64, so a
     # handful of windows in 20 000 sit a little over 1e-4 against ANOTHER f32 evaluation (README says so next
-    # to "within 1e-4").  The bars are the maxima measured over the three modes on MI355X (round 3, r03a:
-    # E. coli 1.05e-4, human 1.20e-4 against the C port; 4.2e-5 against NumPy-f32 on the slice) + 10 %; the
+    # to "within 1e-4").  The bars are the maxima measured over the three modes on MI355X (round 3, r03c:
+    # E. coli 1.07e-4, human 1.20e-4 against the C port; 4.2e-5 against NumPy-f32 on the slice) + 10 %; the
     # kernels are deterministic, so a change here means the arithmetic changed and the numbers are re-measured.
     assert n_over <= 1 and n_mis == 0
-    assert worst_c <= (1.16e-4 if sp == "ecoli" else 1.32e-4)
+    assert worst_c <= (1.18e-4 if sp == "ecoli" else 1.32e-4)
     assert worst_np <= 4.7e-5
 
 
@@ -165,7 +165,7 @@ def test_config_batch_sizes_C2_C3(reads, species_models, sp, batch):
     c2, ca2 = CO.predict(m2.flat(), 11, 5, sw, fw, threads=8)
     e1, e2, flips = float(np.abs(p1 - c1).max()), float(np.abs(p2 - c2).max()), int((a1 != ca1).sum() + (a2 != ca2).sum())
     print(f"MEASURED C2C3 {sp} batch {batch}: max|dp| vs C-f32 m1 {e1:.3e} m2 {e2:.3e}, argmax differences {flips}")
-    # measured maxima over the three modes (r03a): E. coli 2.4e-5, human 9.1e-5; + 10 %
+    # measured maxima over the three modes (r03c): E. coli 2.4e-5, human 9.1e-5; + 10 %
     assert max(e1, e2) <= (2.7e-5 if sp == "ecoli" else 1.0e-4)
     assert flips == 0
 
@@ -354,8 +354,8 @@ def test_full_size_properties_device_api(species_models, sp):
     e2 = float(np.abs(p2[lo:lo + cnt].cpu().numpy() - c2).max())
     flips = int((a1[lo:lo + cnt].cpu().numpy() != ca1).sum() + (a2[lo:lo + cnt].cpu().numpy() != ca2).sum())
     print(f"MEASURED C5 {sp}: max|dp| vs C-f32 read mode m1 {e1:.3e} m2 {e2:.3e}, argmax differences {flips}")
-    # measured maxima over the three modes (r03a): E. coli 1.8e-5, human 3.3e-5; + 10 %
-    assert max(e1, e2) <= (2.0e-5 if sp == "ecoli" else 3.7e-5)
+    # measured maxima over the three modes (r03c): E. coli 1.07e-5, human 4.43e-5; + 10 %
+    assert max(e1, e2) <= (1.2e-5 if sp == "ecoli" else 4.9e-5)
     assert flips == 0
     rv.close()
 
@@ -532,7 +532,7 @@ def test_random_shapes_vs_f32_oracle(species_models, precision):
         p1, p2, a1, a2 = rv.predict_pair(sig, rd)
         q1, q2, b1, b2 = O.predict_pair(a.tensors, b.tensors, sig, rd, np.float32, recurrent_act=act)
         worst = max(worst, float(np.abs(p1 - q1).max()), float(np.abs(p2 - q2).max()))
-        # measured maximum over the three modes (r03a): 2.95e-5; + 10 %
+        # measured maximum over the three modes (r03c): 2.95e-5; + 10 %
         assert np.abs(p1 - q1).max() <= 3.3e-5 and np.abs(p2 - q2).max() <= 3.3e-5, (T, n, batch, act)
         for arr, brr, q in ((a1, b1, q1), (a2, b2, q2)):
             for i in np.nonzero(arr != brr)[0]:
