@@ -159,6 +159,10 @@ int nrv_prof_enable(nrv_handle* h, int on);
 int nrv_prof_read(nrv_handle* h, double* ms_total /*[NRV_N_KERNELS]*/,
                   int64_t* launches /*[NRV_N_KERNELS]*/);
 const char* nrv_kernel_name(int slot);
+/* Mean elapsed time, in microseconds, of an EMPTY bracket (two event records back to back on the handle's stream):
+ * what a bracketed launch's figure contains beyond the kernel's own duration.  bench.py reports it next to the
+ * bracketed figures so that they can be set against a rocprofv3 kernel trace of the same command. */
+int nrv_prof_overhead(nrv_handle* h, double* us);
 
 /* Message of the last failure on this handle (or, with h == NULL, of the last failed
  * nrv_create on this thread).  Never NULL. */

@@ -60,14 +60,16 @@ static bool make_blob(const nrv_weights* w, int T, int C, Blob* b) {
 
 // ---- B-fragment packing ---------------------------------------------------------------------
 // The unroll thresholds this file is compiled with (needed by lstm_layer_kernel) also reach the
-// HOST optimiser, which then fully unrolls the constant-bound packing loops below (an 11-minute
-// host compile).  They run once per nrv_create: keep the optimiser off them.
-#define NRV_HOST_COLD __attribute__((optnone, noinline))
+// HOST optimiser, which would fully unroll the constant-bound packing loops below (an 11-minute
+// host compile).  Every loop of the packing code therefore carries an explicit "do not unroll" - the code
+// is still optimised otherwise (round 2 had the optimiser off altogether: 0.12 s of packing per nrv_create).
+#define NRV_HOST_COLD __attribute__((noinline))
+#define NRV_FOR _Pragma("clang loop unroll(disable)") for
 // One packed k-group for one 32-column tile: dst[lane][j] = get(k = 8*kg + 4*(lane>>5) + j, lane&31)
 template <class G>
 NRV_HOST_COLD static void pack_kgroup(float* dst, int kg, G get) {
-  for (int lane = 0; lane < 64; ++lane)
-    for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = get(8 * kg + 4 * (lane >> 5) + j, lane & 31);
+  NRV_FOR (int lane = 0; lane < 64; ++lane)
+    NRV_FOR (int j = 0; j < 4; ++j) dst[lane * 4 + j] = get(8 * kg + 4 * (lane >> 5) + j, lane & 31);
 }
 
 // Bi-LSTM layer: [dir][hg][kg][gate][64][4] ; bias [dir][hg][gate][32]
@@ -77,13 +79,13 @@ NRV_HOST_COLD static void pack_lstm(const Blob& b, int base, int Kin, int H, std
   const int KG_IN = (Kin + 7) / 8, KG_REC = H / 8, KG = KG_IN + KG_REC;
   wpack.assign((size_t)2 * NG * KG * 4 * 256, 0.f);
   bias.assign((size_t)2 * NG * 4 * 32, 0.f);
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);   // (Kin, 4H)
     const float* U = b.t(base + dir * 3 + 1);   // (H, 4H)
     const float* B = b.t(base + dir * 3 + 2);   // (4H)
-    for (int hg = 0; hg < NG; ++hg) {
-      for (int kg = 0; kg < KG; ++kg)
-        for (int g = 0; g < 4; ++g) {
+    NRV_FOR (int hg = 0; hg < NG; ++hg) {
+      NRV_FOR (int kg = 0; kg < KG; ++kg)
+        NRV_FOR (int g = 0; g < 4; ++g) {
           float* dst = wpack.data() + ((((size_t)(dir * NG + hg) * KG + kg) * 4 + g) * 256);
           pack_kgroup(dst, kg < KG_IN ? kg : kg - KG_IN, [&](int k, int c) -> float {
             int u = hg * 32 + c;
@@ -92,8 +94,8 @@ NRV_HOST_COLD static void pack_lstm(const Blob& b, int base, int Kin, int H, std
             return U[(size_t)k * 4 * H + g * H + u];
           });
         }
-      for (int g = 0; g < 4; ++g)
-        for (int c = 0; c < 32; ++c) {
+      NRV_FOR (int g = 0; g < 4; ++g)
+        NRV_FOR (int c = 0; c < 32; ++c) {
           int u = hg * 32 + c;
           bias[((size_t)(dir * NG + hg) * 4 + g) * 32 + c] = u < H ? B[g * H + u] : 0.f;
         }
@@ -120,14 +122,14 @@ static inline float bf16_to_f32_host(uint16_t b) {
 NRV_HOST_COLD static void pack_lstm_split(const Blob& b, int base, int Kin, int H, std::vector<float>& out) {
   const int NG = (H + 31) / 32, KB_IN = Kin / 16, KB = KB_IN + H / 16;
   std::vector<uint16_t> w((size_t)2 * NG * KB * 4 * 3 * 64 * 8, 0);
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
-    for (int hg = 0; hg < NG; ++hg)
-      for (int kb = 0; kb < KB; ++kb)
-        for (int g = 0; g < 4; ++g)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
+    NRV_FOR (int hg = 0; hg < NG; ++hg)
+      NRV_FOR (int kb = 0; kb < KB; ++kb)
+        NRV_FOR (int g = 0; g < 4; ++g)
+          NRV_FOR (int lane = 0; lane < 64; ++lane)
+            NRV_FOR (int j = 0; j < 8; ++j) {
               const int unit = hg * 32 + (lane & 31);
               float v = 0.f;
               if (unit < H) {
@@ -135,7 +137,7 @@ NRV_HOST_COLD static void pack_lstm_split(const Blob& b, int base, int Kin, int 
                 v = (kb < KB_IN ? W : U)[(size_t)k * 4 * H + g * H + unit];
               }
               float rem = v;
-              for (int tm = 0; tm < 3; ++tm) {
+              NRV_FOR (int tm = 0; tm < 3; ++tm) {
                 const uint16_t q = f32_to_bf16_rne(rem);
                 rem -= bf16_to_f32_host(q);
                 w[((((((size_t)(dir * NG + hg) * KB + kb) * 4 + g) * 3 + tm) * 64) + lane) * 8 + j] = q;
@@ -156,7 +158,7 @@ static int pow2_room(float bound) {
 }
 static float max_abs(const float* p, size_t n) {
   float m = 0.f;
-  for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(p[i]));
+  NRV_FOR (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(p[i]));
   return m;
 }
 // The layer's accumulator exponent E: every operand tensor t enters the matrix pipe as t * 2^(its
@@ -165,7 +167,7 @@ static float max_abs(const float* p, size_t n) {
 // the largest value that keeps every scaled weight block below 2^14.
 static int plan_exponent(const Blob& b, int base, int K0, int s0, int K1, int s1, int H) {
   int E = 1 << 20;
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
     E = std::min(E, s0 + pow2_room(max_abs(W, (size_t)K0 * 4 * H)));
@@ -192,15 +194,15 @@ NRV_HOST_COLD static void pack_lstm_h2(const Blob& b, int base, int K0, int s0, 
   const int NG = (H + upw - 1) / upw, KB_IN = Kin / 16, KB = KB_IN + H / 16;
   std::vector<uint16_t> w((size_t)2 * NG * KB * ngt * 2 * 64 * 8, 0);
   bias.assign((size_t)2 * NG * 4 * upw, 0.f);
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
     const float* B = b.t(base + dir * 3 + 2);
-    for (int hg = 0; hg < NG; ++hg) {
-      for (int kb = 0; kb < KB; ++kb)
-        for (int tl = 0; tl < ngt; ++tl)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
+    NRV_FOR (int hg = 0; hg < NG; ++hg) {
+      NRV_FOR (int kb = 0; kb < KB; ++kb)
+        NRV_FOR (int tl = 0; tl < ngt; ++tl)
+          NRV_FOR (int lane = 0; lane < 64; ++lane)
+            NRV_FOR (int j = 0; j < 8; ++j) {
               const int n = lane & 31, g = tl * gpt + n / upw, unit = hg * upw + n % upw;
               float v = 0.f;
               if (unit < H) {
@@ -211,8 +213,8 @@ NRV_HOST_COLD static void pack_lstm_h2(const Blob& b, int base, int K0, int s0, 
               const size_t o = (((((size_t)(dir * NG + hg) * KB + kb) * ngt + tl) * 2) * 64 + lane) * 8 + j;
               split_f16(v, &w[o], &w[o + 64 * 8]);
             }
-      for (int g = 0; g < 4; ++g)
-        for (int c = 0; c < upw; ++c) {
+      NRV_FOR (int g = 0; g < 4; ++g)
+        NRV_FOR (int c = 0; c < upw; ++c) {
           const int unit = hg * upw + c;
           bias[((size_t)(dir * NG + hg) * 4 + g) * upw + c] = unit < H ? std::ldexp(B[g * H + unit], E) : 0.f;
         }
@@ -230,16 +232,16 @@ NRV_HOST_COLD static void pack_lstm_h2s(const Blob& b, int base, int K0, int s0,
   const int NG = H / (16 * uh), KK_IN = Kin / 32, KK = KK_IN + H / 32, epk = 4 * uh;
   std::vector<uint16_t> w((size_t)2 * NG * KK * epk * 2 * 64 * 8, 0);
   bias.assign((size_t)2 * NG * 4 * 16 * uh, 0.f);
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
     const float* B = b.t(base + dir * 3 + 2);
-    for (int wg = 0; wg < NG; ++wg) {
-      for (int kk = 0; kk < KK; ++kk)
-        for (int g = 0; g < 4; ++g)
-          for (int h = 0; h < uh; ++h)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int j = 0; j < 8; ++j) {
+    NRV_FOR (int wg = 0; wg < NG; ++wg) {
+      NRV_FOR (int kk = 0; kk < KK; ++kk)
+        NRV_FOR (int g = 0; g < 4; ++g)
+          NRV_FOR (int h = 0; h < uh; ++h)
+            NRV_FOR (int lane = 0; lane < 64; ++lane)
+              NRV_FOR (int j = 0; j < 8; ++j) {
                 const int unit = 16 * (wg * uh + h) + (lane & 15);
                 const int k = 32 * (kk < KK_IN ? kk : kk - KK_IN) + 8 * (lane >> 4) + j;
                 float v;
@@ -248,8 +250,8 @@ NRV_HOST_COLD static void pack_lstm_h2s(const Blob& b, int base, int K0, int s0,
                 const size_t o = ((((((size_t)(dir * NG + wg) * KK + kk) * 4 + g) * uh + h) * 2) * 64 + lane) * 8 + j;
                 split_f16(v, &w[o], &w[o + 64 * 8]);
               }
-      for (int g = 0; g < 4; ++g)
-        for (int c = 0; c < 16 * uh; ++c)
+      NRV_FOR (int g = 0; g < 4; ++g)
+        NRV_FOR (int c = 0; c < 16 * uh; ++c)
           bias[((size_t)(dir * NG + wg) * 4 + g) * 16 * uh + c] = std::ldexp(B[g * H + wg * 16 * uh + c], E);
     }
   }
@@ -268,14 +270,14 @@ NRV_HOST_COLD static void pack_lstm2_t(const Blob& b, int base, int s_in, int E,
   constexpr int H = 64, Kin = 32;
   std::vector<uint16_t> w((size_t)2 * 3 * 16 * 2 * 64 * 8, 0);
   bias.assign((size_t)2 * 16 * 64 * 4, 0.f);
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
     const float* B = b.t(base + dir * 3 + 2);
-    for (int kb = 0; kb < 3; ++kb)
-      for (int mt = 0; mt < 16; ++mt)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
+    NRV_FOR (int kb = 0; kb < 3; ++kb)
+      NRV_FOR (int mt = 0; mt < 16; ++mt)
+        NRV_FOR (int lane = 0; lane < 64; ++lane)
+          NRV_FOR (int j = 0; j < 8; ++j) {
             const int g = mt >> 2, ut = mt & 3, u = 16 * ut + (lane & 15), q = lane >> 4;
             float v;
             if (kb == 0) {
@@ -288,9 +290,9 @@ NRV_HOST_COLD static void pack_lstm2_t(const Blob& b, int base, int s_in, int E,
             const size_t o = ((((size_t)(dir * 3 + kb) * 16 + mt) * 2) * 64 + lane) * 8 + j;
             split_f16(v, &w[o], &w[o + 64 * 8]);
           }
-    for (int mt = 0; mt < 16; ++mt)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int r = 0; r < 4; ++r) {
+    NRV_FOR (int mt = 0; mt < 16; ++mt)
+      NRV_FOR (int lane = 0; lane < 64; ++lane)
+        NRV_FOR (int r = 0; r < 4; ++r) {
           const int g = mt >> 2, ut = mt & 3, q = lane >> 4;
           bias[(((size_t)dir * 16 + mt) * 64 + lane) * 4 + r] = std::ldexp(B[g * H + 16 * ut + 4 * q + r], E);
         }
@@ -309,24 +311,24 @@ NRV_HOST_COLD static void pack_head_split(const Blob& b, std::vector<float>& out
   std::vector<uint16_t> w((size_t)126 * 512, 0);
   auto emit = [&](int fragbase, float v, int lane, int j) {
     float rem = v;
-    for (int tm = 0; tm < 3; ++tm) {
+    NRV_FOR (int tm = 0; tm < 3; ++tm) {
       const uint16_t q = f32_to_bf16_rne(rem);
       rem -= bf16_to_f32_host(q);
       w[((size_t)(fragbase + tm) * 64 + lane) * 8 + j] = q;
     }
   };
   const float *W1 = b.t(50), *W2 = b.t(52), *W3 = b.t(54);
-  for (int lane = 0; lane < 64; ++lane)
-    for (int j = 0; j < 8; ++j) {
+  NRV_FOR (int lane = 0; lane < 64; ++lane)
+    NRV_FOR (int j = 0; j < 8; ++j) {
       const int h = lane >> 5, n = lane & 31;
-      for (int mt = 0; mt < 4; ++mt)
-        for (int kb = 0; kb < 8; ++kb)
+      NRV_FOR (int mt = 0; mt < 4; ++mt)
+        NRV_FOR (int kb = 0; kb < 8; ++kb)
           emit((mt * 8 + kb) * 3, W1[(size_t)(16 * kb + 8 * h + j) * 128 + mt * 32 + n], lane, j);
-      for (int kb = 0; kb < 8; ++kb) {
+      NRV_FOR (int kb = 0; kb < 8; ++kb) {
         const int reg = 8 * (kb & 1) + j, f = 32 * (kb >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         emit(96 + kb * 3, W2[(size_t)f * 32 + n], lane, j);
       }
-      for (int kb = 0; kb < 2; ++kb) {
+      NRV_FOR (int kb = 0; kb < 2; ++kb) {
         const int reg = 8 * kb + j, f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
         emit(120 + kb * 3, n < 6 ? W3[(size_t)f * 6 + n] : 0.f, lane, j);
       }
@@ -343,12 +345,12 @@ NRV_HOST_COLD static void pack_head_split(const Blob& b, std::vector<float>& out
 // lane l, element j hold W[k][n] with k = 16*kb + 8*(l>>5) + j (flatten index p*8+o), n = 32*nh + (l&31).
 NRV_HOST_COLD static void pack_cnn_split(const float* W, std::vector<float>& out) {
   std::vector<uint16_t> w((size_t)25 * 2 * 3 * 512, 0);
-  for (int kb = 0; kb < 25; ++kb)
-    for (int nh = 0; nh < 2; ++nh)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int j = 0; j < 8; ++j) {
+  NRV_FOR (int kb = 0; kb < 25; ++kb)
+    NRV_FOR (int nh = 0; nh < 2; ++nh)
+      NRV_FOR (int lane = 0; lane < 64; ++lane)
+        NRV_FOR (int j = 0; j < 8; ++j) {
           float rem = W[(size_t)(16 * kb + 8 * (lane >> 5) + j) * 64 + 32 * nh + (lane & 31)];
-          for (int tm = 0; tm < 3; ++tm) {
+          NRV_FOR (int tm = 0; tm < 3; ++tm) {
             const uint16_t q = f32_to_bf16_rne(rem);
             rem -= bf16_to_f32_host(q);
             w[((size_t)((kb * 2 + nh) * 3 + tm) * 64 + lane) * 8 + j] = q;
@@ -369,14 +371,14 @@ NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>
   const float *W1 = b.t(50), *B1 = b.t(51), *W2 = b.t(52), *B2 = b.t(53), *W3 = b.t(54), *B3 = b.t(55);
   const int u1 = pow2_room(max_abs(W1, 128 * 128)), u2 = pow2_room(max_abs(W2, 128 * 32)), u3 = pow2_room(max_abs(W3, 32 * 6));
   float bound1 = 0.f, bound2 = 0.f;
-  for (int n = 0; n < 128; ++n) {
+  NRV_FOR (int n = 0; n < 128; ++n) {
     float a = std::fabs(B1[n]);
-    for (int k = 0; k < 128; ++k) a += std::fabs(W1[(size_t)k * 128 + n]);
+    NRV_FOR (int k = 0; k < 128; ++k) a += std::fabs(W1[(size_t)k * 128 + n]);
     bound1 = std::fmax(bound1, a);
   }
-  for (int n = 0; n < 32; ++n) {
+  NRV_FOR (int n = 0; n < 32; ++n) {
     float a = std::fabs(B2[n]);
-    for (int k = 0; k < 128; ++k) a += std::fabs(W2[(size_t)k * 32 + n]) * bound1;
+    NRV_FOR (int k = 0; k < 128; ++k) a += std::fabs(W2[(size_t)k * 32 + n]) * bound1;
     bound2 = std::fmax(bound2, a);
   }
   const int s1 = pow2_room(bound1), s2 = pow2_room(bound2);
@@ -386,17 +388,17 @@ NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>
     const size_t o = ((size_t)fragbase * 64 + lane) * 8 + j;
     split_f16(v, &w[o], &w[o + 512]);
   };
-  for (int lane = 0; lane < 64; ++lane)
-    for (int j = 0; j < 8; ++j) {
+  NRV_FOR (int lane = 0; lane < 64; ++lane)
+    NRV_FOR (int j = 0; j < 8; ++j) {
       const int h = lane >> 5, n = lane & 31;
-      for (int mt = 0; mt < 4; ++mt)
-        for (int kb = 0; kb < 8; ++kb)
+      NRV_FOR (int mt = 0; mt < 4; ++mt)
+        NRV_FOR (int kb = 0; kb < 8; ++kb)
           emit((mt * 8 + kb) * 2, std::ldexp(W1[(size_t)(16 * kb + 8 * h + j) * 128 + mt * 32 + n], u1), lane, j);
-      for (int kb = 0; kb < 8; ++kb) {
+      NRV_FOR (int kb = 0; kb < 8; ++kb) {
         const int reg = 8 * (kb & 1) + j, f = 32 * (kb >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         emit(64 + kb * 2, std::ldexp(W2[(size_t)f * 32 + n], u2), lane, j);
       }
-      for (int kb = 0; kb < 2; ++kb) {
+      NRV_FOR (int kb = 0; kb < 2; ++kb) {
         const int reg = 8 * kb + j, f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
         emit(80 + kb * 2, n < 6 ? std::ldexp(W3[(size_t)f * 6 + n], u3) : 0.f, lane, j);
       }
@@ -404,9 +406,9 @@ NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>
   out.assign(w.size() / 2, 0.f);
   memcpy(out.data(), w.data(), w.size() * 2);
   bias.assign(192, 0.f);
-  for (int i = 0; i < 128; ++i) bias[i] = std::ldexp(B1[i], E1);
-  for (int i = 0; i < 32; ++i) bias[128 + i] = std::ldexp(B2[i], E2);
-  for (int i = 0; i < 6; ++i) bias[160 + i] = std::ldexp(B3[i], E3);
+  NRV_FOR (int i = 0; i < 128; ++i) bias[i] = std::ldexp(B1[i], E1);
+  NRV_FOR (int i = 0; i < 32; ++i) bias[128 + i] = std::ldexp(B2[i], E2);
+  NRV_FOR (int i = 0; i < 6; ++i) bias[160 + i] = std::ldexp(B3[i], E3);
   return HeadH2Scales{std::ldexp(1.f, s1 - E1), std::ldexp(1.f, s2 - E2), std::ldexp(1.f, -E3)};
 }
 
@@ -415,10 +417,10 @@ NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>
 // (flatten index p*8+o; rows >= 400 are zero), n = 16*ct + (l&15).
 NRV_HOST_COLD static void pack_cnn_h2(const float* W, int wexp, std::vector<float>& out) {
   std::vector<uint16_t> w((size_t)13 * 4 * 2 * 512, 0);
-  for (int ks = 0; ks < 13; ++ks)
-    for (int ct = 0; ct < 4; ++ct)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int j = 0; j < 8; ++j) {
+  NRV_FOR (int ks = 0; ks < 13; ++ks)
+    NRV_FOR (int ct = 0; ct < 4; ++ct)
+      NRV_FOR (int lane = 0; lane < 64; ++lane)
+        NRV_FOR (int j = 0; j < 8; ++j) {
           const int k = 32 * ks + 8 * (lane >> 4) + j;
           const float v = k < 400 ? std::ldexp(W[(size_t)k * 64 + 16 * ct + (lane & 15)], wexp) : 0.f;
           const size_t o = ((size_t)((ks * 4 + ct) * 2) * 64 + lane) * 8 + j;
@@ -436,23 +438,23 @@ NRV_HOST_COLD static void pack_lstm1_16(const Blob& b, int base, std::vector<flo
   const int H = 16, Kin = 6;
   wpack.assign((size_t)2 * 6 * 4 * 64, 0.f);
   bias.assign((size_t)2 * 4 * 16, 0.f);
-  for (int dir = 0; dir < 2; ++dir) {
+  NRV_FOR (int dir = 0; dir < 2; ++dir) {
     const float* W = b.t(base + dir * 3 + 0);
     const float* U = b.t(base + dir * 3 + 1);
     const float* B = b.t(base + dir * 3 + 2);
-    for (int g = 0; g < 4; ++g) {
-      for (int lane = 0; lane < 64; ++lane) {
+    NRV_FOR (int g = 0; g < 4; ++g) {
+      NRV_FOR (int lane = 0; lane < 64; ++lane) {
         const int q = lane >> 4, c = lane & 15;
-        for (int s = 0; s < 2; ++s) {
+        NRV_FOR (int s = 0; s < 2; ++s) {
           int k = 4 * s + q;
           wpack[(((size_t)dir * 6 + s) * 4 + g) * 64 + lane] = k < Kin ? W[(size_t)k * 4 * H + g * H + c] : 0.f;
         }
-        for (int s = 0; s < 4; ++s) {
+        NRV_FOR (int s = 0; s < 4; ++s) {
           int u = 4 * q + s;
           wpack[(((size_t)dir * 6 + 2 + s) * 4 + g) * 64 + lane] = U[(size_t)u * 4 * H + g * H + c];
         }
       }
-      for (int c = 0; c < 16; ++c) bias[((size_t)dir * 4 + g) * 16 + c] = B[g * H + c];
+      NRV_FOR (int c = 0; c < 16; ++c) bias[((size_t)dir * 4 + g) * 16 + c] = B[g * H + c];
     }
   }
 }
@@ -461,8 +463,8 @@ NRV_HOST_COLD static void pack_lstm1_16(const Blob& b, int base, std::vector<flo
 NRV_HOST_COLD static void pack_dense(const float* W, int K, int N, std::vector<float>& out) {
   const int NT = (N + 31) / 32, KG = (K + 7) / 8;
   out.assign((size_t)NT * KG * 256, 0.f);
-  for (int nt = 0; nt < NT; ++nt)
-    for (int kg = 0; kg < KG; ++kg)
+  NRV_FOR (int nt = 0; nt < NT; ++nt)
+    NRV_FOR (int kg = 0; kg < KG; ++kg)
       pack_kgroup(out.data() + ((size_t)nt * KG + kg) * 256, kg, [&](int k, int c) -> float {
         int col = nt * 32 + c;
         return (k < K && col < N) ? W[(size_t)k * N + col] : 0.f;
@@ -474,10 +476,10 @@ NRV_HOST_COLD static void pack_dense(const float* W, int K, int N, std::vector<f
 NRV_HOST_COLD static void pack_dense16(const float* W, int K, int N, std::vector<float>& out) {
   const int CT = (N + 15) / 16, KG = (K + 15) / 16;
   out.assign((size_t)CT * KG * 256, 0.f);
-  for (int ct = 0; ct < CT; ++ct)
-    for (int kg = 0; kg < KG; ++kg)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int j = 0; j < 4; ++j) {
+  NRV_FOR (int ct = 0; ct < CT; ++ct)
+    NRV_FOR (int kg = 0; kg < KG; ++kg)
+      NRV_FOR (int lane = 0; lane < 64; ++lane)
+        NRV_FOR (int j = 0; j < 4; ++j) {
           int k = 16 * kg + 4 * (lane >> 4) + j, col = 16 * ct + (lane & 15);
           out[((size_t)ct * KG + kg) * 256 + lane * 4 + j] = (k < K && col < N) ? W[(size_t)k * N + col] : 0.f;
         }
@@ -486,7 +488,7 @@ NRV_HOST_COLD static void pack_dense16(const float* W, int K, int N, std::vector
 // Keras inference BatchNorm as scale/shift:  x*inv + (beta - mean*inv), inv = gamma/sqrt(var+eps)
 static void bn_fold(const float* g, const float* be, const float* mu, const float* var, int n,
                     float* scale, float* shift) {
-  for (int i = 0; i < n; ++i) {
+  NRV_FOR (int i = 0; i < n; ++i) {
     float inv = g[i] / std::sqrt(var[i] + 1e-3f);
     scale[i] = inv;
     shift[i] = be[i] - mu[i] * inv;
@@ -632,7 +634,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
   d.dsplit = put(wp.data(), wp.size());
   const int lbase[4] = {12, 22, 34, 44}, lK[4] = {6, 32, 192, 256}, lH[4] = {16, 64, 128, 64};
   const int bnbase[4] = {18, 28, 40, -1};
-  for (int l = 0; l < 4; ++l) {
+  NRV_FOR (int l = 0; l < 4; ++l) {
     pack_lstm(b, lbase[l], lK[l], lH[l], wp, bs);
     d.l_w[l] = put(wp.data(), wp.size());
     d.l_b[l] = put(bs.data(), bs.size());
@@ -643,7 +645,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     d.l_s[l] = put(sc.data(), sc.size());
     d.l_h[l] = put(sh.data(), sh.size());
   }
-  for (int l = 1; l < 4; ++l) {
+  NRV_FOR (int l = 1; l < 4; ++l) {
     pack_lstm_split(b, lbase[l], lK[l], lH[l], wp);
     d.l_ws[l] = put(wp.data(), wp.size());
   }
@@ -655,7 +657,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       sc.assign(n, 1.f); sh.assign(n, 0.f);
       bn_fold(b.t(bnb), b.t(bnb + 1), b.t(bnb + 2), b.t(bnb + 3), n, sc.data(), sh.data());
       float bound = 0.f;
-      for (int i = 0; i < n; ++i) bound = std::fmax(bound, std::fabs(sc[i]) + std::fabs(sh[i]));
+      NRV_FOR (int i = 0; i < n; ++i) bound = std::fmax(bound, std::fabs(sc[i]) + std::fabs(sh[i]));
       return pow2_room(bound);
     };
     std::vector<float> sc1, sh1, sc2, sh2, sc3, sh3;
@@ -663,7 +665,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     constexpr int sS = 6;
     auto put_scaled = [&](const std::vector<float>& v, int e) {
       std::vector<float> t(v.size());
-      for (size_t i = 0; i < v.size(); ++i) t[i] = std::ldexp(v[i], e);
+      NRV_FOR (size_t i = 0; i < v.size(); ++i) t[i] = std::ldexp(v[i], e);
       return put(t.data(), t.size());
     };
     d.l1s2 = put_scaled(sc1, sX1);                       // lstm1 keeps h unscaled in its LDS image
@@ -673,7 +675,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       static_assert(sS == 6, "kImgScale / kDenseDescale in nrv_cnn_f16x2.h assume S x 2^6");
       float cv[264];
       memcpy(cv, host.data() + d.conv, 264 * 4);
-      for (int o = 0; o < 8; ++o) { cv[248 + o] = std::ldexp(cv[248 + o], 6); cv[256 + o] = std::ldexp(cv[256 + o], 6); }
+      NRV_FOR (int o = 0; o < 8; ++o) { cv[248 + o] = std::ldexp(cv[248 + o], 6); cv[256 + o] = std::ldexp(cv[256 + o], 6); }
       d.conv_h2 = put(cv, 264);
       pack_cnn_h2(b.t(32), 10, wp);
       d.dsplit_h2 = put(wp.data(), wp.size());
@@ -684,8 +686,8 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       const float* w2 = host.data() + d.conv + 48;             // [tap][ci][co]
       const int u = pow2_room(max_abs(w2, 192));
       std::vector<uint16_t> frag((size_t)2 * 64 * 8, 0);
-      for (int lane = 0; lane < 64; ++lane)
-        for (int j = 0; j < 8; ++j) {
+      NRV_FOR (int lane = 0; lane < 64; ++lane)
+        NRV_FOR (int j = 0; j < 8; ++j) {
           const int co = lane & 15, tap = lane >> 4;
           const float v = (co < 8 && tap < 3) ? std::ldexp(w2[(tap * 8 + j) * 8 + co], u) : 0.f;
           split_f16(v, &frag[(size_t)lane * 8 + j], &frag[(size_t)512 + lane * 8 + j]);
@@ -694,7 +696,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       memcpy(ff.data(), frag.data(), frag.size() * 2);
       d.cm_w2 = put(ff.data(), ff.size());
       float ep[48] = {0};
-      for (int co = 0; co < 8; ++co) {
+      NRV_FOR (int co = 0; co < 8; ++co) {
         ep[co] = std::ldexp(cv[240 + co], 6 + u);              // bias of the second convolution
         ep[16 + co] = std::ldexp(cv[248 + co], -6 - u);        // cv[248..]: BatchNorm 2 scale, already x 2^6 -> s2 x 2^-u
         ep[32 + co] = cv[256 + co];                            // BatchNorm 2 shift x 2^6
@@ -704,8 +706,8 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
         // cnn_r_kernel (nrv_cnn_r.h).  conv2's A operand gives TWO positions per product: rows 0-7 take tap = k-group,
         // rows 8-15 tap = k-group - 1 (the B operand's k-groups hold c1 at positions p - 1 .. p + 2).
         std::vector<uint16_t> fr((size_t)2 * 64 * 8, 0);
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
+        NRV_FOR (int lane = 0; lane < 64; ++lane)
+          NRV_FOR (int j = 0; j < 8; ++j) {
             const int m = lane & 15, kg = lane >> 4;
             const int co = m & 7, tap = m < 8 ? kg : kg - 1;
             const float v = (tap >= 0 && tap < 3) ? std::ldexp(w2[(tap * 8 + j) * 8 + co], u) : 0.f;
@@ -715,17 +717,17 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
         memcpy(f2.data(), fr.data(), fr.size() * 2);
         d.cr_w2 = put(f2.data(), f2.size());
         float e2[24];
-        for (int co = 0; co < 8; ++co) { e2[co] = ep[co]; e2[8 + co] = ep[16 + co]; e2[16 + co] = ep[32 + co]; }
+        NRV_FOR (int co = 0; co < 8; ++co) { e2[co] = ep[co]; e2[8 + co] = ep[16 + co]; e2[16 + co] = ep[32 + co]; }
         d.cr_ep = put(e2, 24);
         // dense 400 -> 64 x 2^10 as A fragments in the k order the conv2 result tiles arrive in:
         // [ks 13][mt 4][term 2][64 lanes][8 f16]; lane (m = l & 15, kg = l >> 4), element j:
         //   position 4 ks + 2 (j >> 2) + (kg >> 1), channel 4 (kg & 1) + (j & 3), output feature 16 mt + m
         const float* Wd = b.t(32);
         std::vector<uint16_t> df((size_t)13 * 4 * 2 * 512, 0);
-        for (int ks = 0; ks < 13; ++ks)
-          for (int mt = 0; mt < 4; ++mt)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int j = 0; j < 8; ++j) {
+        NRV_FOR (int ks = 0; ks < 13; ++ks)
+          NRV_FOR (int mt = 0; mt < 4; ++mt)
+            NRV_FOR (int lane = 0; lane < 64; ++lane)
+              NRV_FOR (int j = 0; j < 8; ++j) {
                 const int m = lane & 15, kg = lane >> 4;
                 const int pos = 4 * ks + 2 * (j >> 2) + (kg >> 1), ch = 4 * (kg & 1) + (j & 3);
                 const float v = pos < 50 ? std::ldexp(Wd[(size_t)(pos * 8 + ch) * 64 + 16 * mt + m], 10) : 0.f;
@@ -739,7 +741,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
       const float* c0 = host.data() + d.conv;                  // unscaled: w1 24, b1 8, s1 8, h1 8
       memcpy(d.cr_k.w1, c0, 24 * 4);
       memcpy(d.cr_k.b1, c0 + 24, 8 * 4);
-      for (int o = 0; o < 8; ++o) { d.cr_k.s1[o] = std::ldexp(c0[32 + o], 6); d.cr_k.h1[o] = std::ldexp(c0[40 + o], 6); }
+      NRV_FOR (int o = 0; o < 8; ++o) { d.cr_k.s1[o] = std::ldexp(c0[32 + o], 6); d.cr_k.h1[o] = std::ldexp(c0[40 + o], 6); }
     }
     const int K0[4] = {0, 32, 128, 256}, K1[4] = {0, 0, 64, 0}, s0[4] = {0, sX1, sX2, sX3}, s1[4] = {0, 0, sS, 0};
     const std::vector<float>* osc[4] = {nullptr, &sc2, &sc3, nullptr};
@@ -748,7 +750,7 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     d.hsc = pack_head_h2(b, wp, bs);
     d.h_w2 = put(wp.data(), wp.size());
     d.h_b2 = put(bs.data(), bs.size());
-    for (int l = 1; l < 4; ++l) {
+    NRV_FOR (int l = 1; l < 4; ++l) {
       const int E = plan_exponent(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l]);
       pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs);
       d.l_w2[l] = put(wp.data(), wp.size());
@@ -775,17 +777,17 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
         const std::vector<float>& fsc = l == 2 ? sc2 : sc3;
         const std::vector<float>& fsh = l == 2 ? sh2 : sh3;
         std::vector<float> all(b.p, b.p + b.off.back() + (size_t)C);          // the blob ends with final_out's bias [C]
-        for (int dir = 0; dir < 2; ++dir) {
+        NRV_FOR (int dir = 0; dir < 2; ++dir) {
           float* W = all.data() + b.off[lbase[l] + dir * 3 + 0];
           float* B = all.data() + b.off[lbase[l] + dir * 3 + 2];
           const int N4 = 4 * lH[l];
-          for (int c = 0; c < N4; ++c) {
+          NRV_FOR (int c = 0; c < N4; ++c) {
             double acc = B[c];
-            for (int k = 0; k < Kf; ++k) acc += (double)fsh[k] * (double)W[(size_t)k * N4 + c];
+            NRV_FOR (int k = 0; k < Kf; ++k) acc += (double)fsh[k] * (double)W[(size_t)k * N4 + c];
             B[c] = (float)acc;
           }
-          for (int k = 0; k < Kf; ++k)
-            for (int c = 0; c < N4; ++c) W[(size_t)k * N4 + c] *= fsc[k];
+          NRV_FOR (int k = 0; k < Kf; ++k)
+            NRV_FOR (int c = 0; c < N4; ++c) W[(size_t)k * N4 + c] *= fsc[k];
         }
         const Blob bf{all.data(), b.off};
         const int Ef = plan_exponent(bf, lbase[l], K0[l], 13, K1[l], s1[l], lH[l]);
@@ -1834,6 +1836,28 @@ int nrv_prof_read(nrv_handle* h, double* ms_total, int64_t* launches) {
     h->prof_ms[k] = 0;
     h->prof_n[k] = 0;
   }
+  return NRV_OK;
+}
+
+int nrv_prof_overhead(nrv_handle* h, double* us) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!us) { h->err = "nrv_prof_overhead: null output"; return NRV_E_INVALID; }
+  // what a bracket measures beyond the kernel it encloses: two event records back to back on the launch stream
+  constexpr int N = 64;
+  hipEvent_t ev[2 * N];
+  for (int i = 0; i < 2 * N; ++i) HIPCHK(h, hipEventCreate(&ev[i]));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 2 * N; ++i) HIPCHK(h, hipEventRecord(ev[i], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double tot = 0;
+  for (int i = 0; i < N; ++i) {
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    tot += ms;
+  }
+  for (int i = 0; i < 2 * N; ++i) (void)hipEventDestroy(ev[i]);
+  *us = tot / N * 1e3;
   return NRV_OK;
 }
 

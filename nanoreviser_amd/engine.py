@@ -32,7 +32,7 @@ SYMBOLS = [
     "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
     "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
     "nrv_window", "nrv_set_precision", "nrv_get_precision", "nrv_predict_reads_raw", "nrv_segment_reads",
-    "nrv_device_count", "nrv_saturated",
+    "nrv_device_count", "nrv_saturated", "nrv_prof_overhead",
 ]
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x2": 2}
@@ -133,6 +133,7 @@ def load_library(path: Optional[str] = None):
     i16p, i32p, rdp = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(_ReadDesc)
     lib.nrv_predict_reads_raw.argtypes = [vp, i16p, C.c_int64, i32p, fp, C.c_int64, rdp, C.c_int, fp, fp, i8p, i8p]
     lib.nrv_segment_reads.argtypes = [vp, i16p, C.c_int64, i32p, C.c_int64, rdp, C.c_int, fp]
+    lib.nrv_prof_overhead.argtypes = [vp, C.POINTER(C.c_double)]
     lib.nrv_saturated.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nrv_set_precision.argtypes = [vp, C.c_int]
     lib.nrv_get_precision.argtypes = [vp]
@@ -400,6 +401,12 @@ class Reviser:
         cnt = (C.c_int64 * N_KERNELS)()
         self._check(self._lib.nrv_prof_read(self._h, ms, cnt))
         return {self._lib.nrv_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(N_KERNELS)}
+
+    def prof_overhead_us(self) -> float:
+        """Microseconds an EMPTY event bracket measures on the launch stream (include/nanorev.h nrv_prof_overhead)."""
+        us = C.c_double(0)
+        self._check(self._lib.nrv_prof_overhead(self._h, C.byref(us)))
+        return float(us.value)
 
     @property
     def backend(self) -> str:
