@@ -326,7 +326,7 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
 
 def load_traffic(T, batch, precision):
     """HBM bytes per lstm3 launch from the committed PMC pass (profiles/*.json), else None."""
-    for name in ("r02_pmc_lstm3.json", "r01_pmc_lstm3.json"):
+    for name in ("r03_pmc_lstm3.json", "r02_pmc_lstm3.json", "r01_pmc_lstm3.json"):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
             j = j.get(precision)

@@ -21,6 +21,12 @@ def short(name):
             ", ".join(m.groups()), name)
     if "lstm1_kernel" in name:
         return "lstm1"
+    if "lstm2_t_kernel" in name:
+        return "lstm2"
+    if "cnn_r_kernel" in name:
+        return "cnn_r_kernel"
+    if "cnn_m_kernel" in name:
+        return "cnn_m_kernel"
     if "head_h2_kernel" in name:
         return "head_h2_kernel"
     if "head_mlp_split_kernel" in name:
