@@ -155,15 +155,27 @@ def predict_one(reviser, rt):
     return reviser.predict_read(rt.sig_ev, rt.feat_ev)
 
 
-def predict_many(reviser, rts):
+def prepare_many(reviser_cls, rts, T):
+    """The NumPy half of `predict_many` for raw reads (concatenation, descriptors, output arrays), done outside the
+    engine thread; None when the batch cannot take the packed path (mixed tensor kinds, an engine without it)."""
+    pack = getattr(reviser_cls, "pack_reads_raw", None)
+    if pack is None or not all(isinstance(rt, hs.RawReadTensors) for rt in rts):
+        return None
+    return pack([rt.raw for rt in rts], [rt.starts for rt in rts], [rt.feat_ev for rt in rts],
+                [rt.shift for rt in rts], [rt.scale for rt in rts], T)
+
+
+def predict_many(reviser, rts, packed=None):
     """Several reads in ONE device call: their per-event arrays are concatenated, the engine forms
     every sliding window of the concatenation, and the T windows that straddle each read boundary
     are simply not used (0.2 % extra work; full launch groups, one host<->device round trip).
     Returns one (p1, p2, a1, a2) per read."""
-    if len(rts) == 1:
+    if len(rts) == 1 and packed is None:
         return [predict_one(reviser, rts[0])]
     T = reviser.T
-    if all(isinstance(rt, hs.RawReadTensors) for rt in rts):
+    if packed is not None:
+        p1, p2, a1, a2 = reviser.run_packed_raw(packed)
+    elif all(isinstance(rt, hs.RawReadTensors) for rt in rts):
         # raw samples + event starts cross PCIe; the (N,50) windows are cut on the device
         p1, p2, a1, a2 = reviser.predict_reads_raw([rt.raw for rt in rts], [rt.starts for rt in rts],
                                                    [rt.feat_ev for rt in rts], [rt.shift for rt in rts],
@@ -208,6 +220,54 @@ def _load_one(job):
         return fn, hs.ReadTensors(None, None, rd.bases, 0.0, 0.0), fq, repr(e), time.perf_counter() - t0
 
 
+class _LightRead:
+    """What the finisher needs of a read whose arrays travel inside a bundle: the original bases."""
+    __slots__ = ("bases", "n_ev")
+
+    def __init__(self, bases, n_ev):
+        self.bases, self.n_ev = bases, n_ev
+
+
+def _load_bundle(jobs):
+    """Worker-process side of the host stage for SEVERAL files: every read through `_load_one`, and the raw reads
+    among them concatenated here into the arrays of ONE device call (samples, event starts, event features, one row
+    of (raw_len, ev_len, shift, scale) per read), so that the main process neither unpickles thousands of small
+    arrays nor concatenates them: a bundle is four big arrays.  Returns (entries, bundle): entries are
+    `_load_one`'s tuples, with the tensors of bundled reads replaced by a `_LightRead`; bundle is None when no read
+    qualified."""
+    entries, good = [], []
+    for j in jobs:
+        fn, rt, fq, err, dt = _load_one(j)
+        if err is None and isinstance(rt, hs.RawReadTensors):
+            good.append(len(entries))
+        entries.append([fn, rt, fq, err, dt])
+    if not good:
+        return [tuple(e) for e in entries], None
+    rts = [entries[i][1] for i in good]
+    bundle = {
+        "idx": good,
+        "raw": np.concatenate([np.ascontiguousarray(r.raw, dtype=np.int16) for r in rts]),
+        "starts": np.concatenate([np.ascontiguousarray(r.starts, dtype=np.int32) for r in rts]),
+        "feat": np.concatenate([np.asarray(r.feat_ev, np.float32).reshape(-1, 6) for r in rts]),
+        "meta": np.array([[len(r.raw), len(r.starts), r.shift, r.scale] for r in rts], np.float64),
+    }
+    for i, r in zip(good, rts):
+        entries[i][1] = _LightRead(r.bases, len(r.starts))
+    return [tuple(e) for e in entries], bundle
+
+
+def _bundle_reads(bundle):
+    """The reads of a bundle as RawReadTensors VIEWS (per-read retries after a failed batched call)."""
+    out, ro, eo = [], 0, 0
+    for rl, el, sh, sc in bundle["meta"]:
+        rl, el = int(rl), int(el)
+        out.append(hs.RawReadTensors(bundle["raw"][ro:ro + rl], bundle["starts"][eo:eo + el],
+                                     bundle["feat"][eo:eo + el], None, float(sh), float(sc)))
+        ro += rl
+        eo += el
+    return out
+
+
 def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
     os.makedirs(args.output_dir, exist_ok=True)
     if args.output_format == "fastq":
@@ -231,22 +291,33 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     basecalls after a failure; revised=False also for files that could not be parsed at all)."""
     stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
     note = on_file or (lambda fn, ok: None)
+    # `reviser` may be a zero-argument factory: the engine is then created by the engine thread as its first task,
+    # i.e. WHILE the parser pool starts and the first reads are parsed (nrv_create: HIP context + weight packing,
+    # 0.15-0.3 s that used to precede everything else)
+    lazy = callable(reviser) and not hasattr(reviser, "predict_read")
+    box = {"rv": None if lazy else reviser}
     nworkers = max(1, min(int(args.thread), os.cpu_count() or 1, 32, max(1, len(files))))
     jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup)
             for fn in files]
 
+    # Files per worker task: one task = one device call (>= kBatchEvents events at ~6.5 k events per read); the
+    # worker hands back the reads of a task already concatenated (`_load_bundle`).
+    kBatchEvents = 8 * max(int(getattr(args, "batch", 4096)), 1024)
+    per_task = max(1, min(16, kBatchEvents // 6500))
+
     def results():
+        """Yields (entries, bundle): `_load_one` tuples, and for pooled tasks their pre-concatenated raw reads."""
         if nworkers == 1 or len(files) < 4:
             for j in jobs:
-                yield _load_one(j)
+                yield [_load_one(j)], None
             return
         import multiprocessing as mp
         from collections import deque
         with ProcessPoolExecutor(nworkers, mp_context=mp.get_context("spawn")) as pool:
-            pend, it = deque(), iter(jobs)
-            for j in it:
-                pend.append(pool.submit(_load_one, j))
-                if len(pend) >= 4 * nworkers:
+            pend = deque()
+            for k in range(0, len(jobs), per_task):
+                pend.append(pool.submit(_load_bundle, jobs[k:k + per_task]))
+                if len(pend) >= 3 * nworkers:
                     yield pend.popleft().result()
             while pend:
                 yield pend.popleft().result()
@@ -269,6 +340,7 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
 
     def finish_batch(batch, calls):
         """Finisher thread: merge + write per read (NumPy + file IO; overlaps the next device call)."""
+        reviser = box["rv"]
         for (fn, rt, fq), c in zip(batch, calls):
             if isinstance(c, Exception):
                 fallback(fn, rt, fq, c)
@@ -285,14 +357,24 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             except Exception as e:
                 fallback(fn, rt, fq, e)
 
-    def run_batch(batch):
+    def run_batch(batch, packed=None, bundle=None):
         """Engine thread: one device call for the batch; merging and writing go to the finisher."""
+        reviser = box["rv"]
         t0 = time.perf_counter()
+        rts = _bundle_reads(bundle) if bundle is not None else [rt for _, rt, _ in batch]
         try:
-            calls = predict_many(reviser, [rt for _, rt, _ in batch])
+            if bundle is not None and packed is not None:
+                p1, p2, a1, a2 = reviser.run_packed_raw(packed)
+                calls, e0, T = [], 0, reviser.T
+                for rl, el, _, _ in bundle["meta"]:        # window i of a read == window e0 + i of the bundle
+                    n = max(int(el) - T, 0)
+                    calls.append((p1[e0:e0 + n], p2[e0:e0 + n], a1[e0:e0 + n], a2[e0:e0 + n]))
+                    e0 += int(el)
+            else:
+                calls = predict_many(reviser, rts, packed)
         except Exception:
             calls = []
-            for fn, rt, fq in batch:                 # isolate the failing read(s)
+            for rt in rts:                           # isolate the failing read(s)
                 try:
                     calls.append(predict_one(reviser, rt))
                 except Exception as e:
@@ -302,34 +384,64 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
 
     # reads are grouped into device calls of >= kBatchEvents events; the engine runs in its own
     # thread (the C-ABI call releases the GIL) so unpickling the next reads overlaps the device
-    kBatchEvents = 8 * max(int(getattr(args, "batch", 4096)), 1024)
     from concurrent.futures import ThreadPoolExecutor
     from collections import deque
     inflight = deque()
     with ThreadPoolExecutor(1) as eng, ThreadPoolExecutor(1) as fin:
+        created = eng.submit(lambda: box.__setitem__("rv", reviser())) if lazy else None
+
+        def submit(batch, bundle=None):
+            # the NumPy half of the device call (descriptors, output arrays; for unbundled reads also the concatenation)
+            # happens HERE, in the main thread, while the engine thread is inside the previous batch's call
+            if created is not None:
+                created.result()                      # raises what the factory raised: loud, no fallback engine
+            rv = box["rv"]
+            packed = None
+            try:
+                if bundle is not None and hasattr(rv, "run_packed_raw"):
+                    packed = type(rv).pack_bundle(bundle["raw"], bundle["starts"], bundle["feat"], bundle["meta"], rv.T)
+                elif bundle is None and len(batch) > 1:
+                    packed = prepare_many(type(rv), [rt for _, rt, _ in batch], rv.T)
+            except Exception:
+                packed = None
+            return eng.submit(run_batch, batch, packed, bundle)
+
+        def drain(limit):
+            while len(inflight) > limit:
+                inflight.popleft().result().result()
+
         batch, nev = [], 0
-        for fn, rt, fq, err, dt in results():
-            stats["host_s"] += dt
-            stats["reads"] += 1
-            if rt is None:
-                log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {err}")
-                stats["failed"].append(fn)
-                note(fn, False)
-                continue
-            if err is not None:
-                fallback(fn, rt, fq, err)
-                continue
-            batch.append((fn, rt, fq))
-            nev += len(rt.feat_ev)
-            if nev >= kBatchEvents:
-                inflight.append(eng.submit(run_batch, batch))
-                batch, nev = [], 0
-                while len(inflight) > 2:
-                    inflight.popleft().result().result()
+        for entries, bundle in results():
+            bundled = []
+            for k, (fn, rt, fq, err, dt) in enumerate(entries):
+                stats["host_s"] += dt
+                stats["reads"] += 1
+                if rt is None:
+                    log(f"！！！[Error] fast5 file: {fn.split('.')[0]} {err}")
+                    stats["failed"].append(fn)
+                    note(fn, False)
+                    continue
+                if err is not None:
+                    fallback(fn, rt, fq, err)
+                    continue
+                if bundle is not None and k in bundle["idx"]:
+                    bundled.append((fn, rt, fq))
+                    continue
+                batch.append((fn, rt, fq))           # unbundled reads (sequential mode, non-int16 signals)
+                nev += len(rt.feat_ev)
+                if nev >= kBatchEvents:
+                    inflight.append(submit(batch))
+                    batch, nev = [], 0
+                    drain(2)
+            if bundled:
+                inflight.append(submit(bundled, bundle))
+                drain(2)
         if batch:
-            inflight.append(eng.submit(run_batch, batch))
-        while inflight:
-            inflight.popleft().result().result()
+            inflight.append(submit(batch))
+        drain(0)
+        if created is not None:
+            created.result()
+    reviser = box["rv"]
     sat = getattr(reviser, "saturated", None)
     if callable(sat):                                 # f16x2 range guard: stages re-run on the f32 kernels
         stats["range_reruns"] = int(sat()[1])
@@ -459,9 +571,14 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         sizes = [os.path.getsize(os.path.join(args.fast5_base_dir, f)) for f in names]
         parts = shard_reads(sizes, world)
         if world == 1:
-            rv = (worker_factory or _default_factory)(args, 0)
-            stats = [process_files(args, names, rv, print)]
-            rv.close()
+            made = []
+
+            def make():                               # runs in the engine thread, beside the parser pool's start-up
+                made.append((worker_factory or _default_factory)(args, 0))
+                return made[0]
+            stats = [process_files(args, names, make, print)]
+            for rv in made:
+                rv.close()
         else:
             shards = [[names[i] for i in parts[r]] for r in range(world)]
             res = run_workers(args, shards, worker_factory)

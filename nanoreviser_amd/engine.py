@@ -273,27 +273,56 @@ class Reviser:
         st = np.concatenate(starts) if starts else np.zeros(0, np.int32)
         return raw, st, descs, len(raws)
 
-    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
-        """Reads given as raw int16 samples (from their first event on), int32 event starts, (N,6)
-        event features and the read's shift / scale; the signal windows are cut on the device.
-        Returns the outputs of `predict_read` on the concatenated per-event arrays (sum(N) - T rows)."""
-        raw, st, descs, nr = self._pack_raw(raws, starts, shifts, scales)
+    @classmethod
+    def pack_reads_raw(cls, raws, starts, feats, shifts, scales, T: int):
+        """Host-side preparation of a `predict_reads_raw` call (concatenation, descriptors, output arrays): pure
+        NumPy, needs no engine - the command line does it in one thread while the engine thread is inside the
+        previous batch's device call.  Returns the tuple `run_packed_raw` takes."""
+        raw, st, descs, nr = cls._pack_raw(raws, starts, shifts, scales)
         feat = _as_f32(np.concatenate([np.asarray(f, np.float32).reshape(-1, 6) for f in feats])
                        if len(feats) else np.zeros((0, 6), np.float32), (6,))
         N = feat.shape[0]
         if st.size != N:
             raise ValueError("starts / feats length mismatch")
-        n = max(N - self.T, 0)
-        p1 = np.empty((n, 6), np.float32)
-        p2 = np.empty((n, 5), np.float32)
-        a1 = np.empty(n, np.int8)
-        a2 = np.empty(n, np.int8)
+        n = max(N - T, 0)
+        out = (np.empty((n, 6), np.float32), np.empty((n, 5), np.float32), np.empty(n, np.int8), np.empty(n, np.int8))
+        return raw, st, feat, descs, nr, N, out
+
+    @staticmethod
+    def pack_bundle(raw, starts, feat, meta, T: int):
+        """`pack_reads_raw` for arrays that are ALREADY concatenated (the command line's worker processes do that):
+        meta is one row (raw_len, ev_len, shift, scale) per read.  Builds the descriptors and the output arrays."""
+        nr = len(meta)
+        descs = (_ReadDesc * max(nr, 1))()
+        ro = eo = 0
+        for i, (rl, el, sh, sc) in enumerate(meta):
+            descs[i] = _ReadDesc(ro, int(rl), eo, int(el), float(sh), float(sc))
+            ro += int(rl)
+            eo += int(el)
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        st = np.ascontiguousarray(starts, dtype=np.int32)
+        feat = _as_f32(feat, (6,))
+        if ro != raw.size or eo != st.size or eo != feat.shape[0]:
+            raise ValueError("bundle arrays do not match their read table")
+        n = max(eo - T, 0)
+        out = (np.empty((n, 6), np.float32), np.empty((n, 5), np.float32), np.empty(n, np.int8), np.empty(n, np.int8))
+        return raw, st, feat, descs, nr, eo, out
+
+    def run_packed_raw(self, packed):
+        """The device call of `predict_reads_raw` on what `pack_reads_raw` prepared."""
+        raw, st, feat, descs, nr, N, (p1, p2, a1, a2) = packed
         fp, i8p = C.POINTER(C.c_float), C.POINTER(C.c_int8)
         self._check(self._lib.nrv_predict_reads_raw(
             self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), raw.size, st.ctypes.data_as(C.POINTER(C.c_int32)),
             feat.ctypes.data_as(fp), N, descs, nr,
             p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p)))
         return p1, p2, a1, a2
+
+    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
+        """Reads given as raw int16 samples (from their first event on), int32 event starts, (N,6)
+        event features and the read's shift / scale; the signal windows are cut on the device.
+        Returns the outputs of `predict_read` on the concatenated per-event arrays (sum(N) - T rows)."""
+        return self.run_packed_raw(self.pack_reads_raw(raws, starts, feats, shifts, scales, self.T))
 
     def segment_reads(self, raws, starts, shifts, scales):
         """The device-side signal segmentation alone: (sum(N), 50) float32."""

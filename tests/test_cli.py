@@ -170,6 +170,41 @@ def test_dead_worker_bookkeeping_uses_reported_files_not_file_existence(tmp_path
     assert not [f for f in os.listdir(out) if ".tmp" in f]
 
 
+@pytest.mark.parametrize("fail", [False, True])
+def test_pooled_workers_hand_over_bundles(tmp_path, fail):
+    """With a parser pool the worker processes concatenate the reads of a task themselves (cli._load_bundle) and
+    the main process issues one device call per bundle.  Same file contract; and when the bundled call fails the
+    reads are retried one by one from views of the bundle, so only the failing read falls back to its original
+    bases and is listed as failed."""
+    import shutil
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    names = [f"b{i}_{'AB'[i % 2]}" for i in range(10)]
+    for n in names:
+        shutil.copy(src[0] if n.endswith("A") else src[1], d / (n + ".fast5"))
+    out = str(tmp_path) + "/o/"
+    marker = None
+    if fail:                                                           # every call that STARTS with a read A fails
+        _, _, rtA = load_read("_".join(os.path.basename(src[0]).split("_")[-3:-1]))
+        marker = rtA.feat_ev[0]
+    eng = EchoEngine(fail_marker=marker)
+    rc = cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "2", "-e", "bad.txt"],
+                  reviser_factory=lambda args, dev: eng)
+    assert rc == 0
+    orig = {"A": _orig(os.path.basename(src[0])), "B": _orig(os.path.basename(src[1]))}
+    for n in names:
+        assert open(out + n + "_out.fasta").read() == ">" + n + ".fast5\n" + orig[n[-1]]
+    failed = sorted(open(out + "bad.txt").read().split())
+    if fail:
+        # a bundle that starts with a read A fails as a whole and is retried read by read: its A reads fail again,
+        # its B reads are revised; bundles that start with a B go through untouched (the task size decides which)
+        assert failed and all(f[:-6].endswith("A") for f in failed) and "b0_A.fast5" in failed
+    else:
+        assert failed == []
+    assert eng.calls >= 2                                              # at least two bundles (+ retries)
+
+
 def test_vlen_string_fastq_does_not_discard_the_read(monkeypatch):
     """h5lite returns str for variable-length string datasets: parse_read must take both."""
     from nanoreviser_amd import h5lite
