@@ -268,6 +268,38 @@ def _bundle_reads(bundle):
     return out
 
 
+class _OutSpec:
+    """The part of the parsed arguments `write_read` needs (picklable, for the worker processes)."""
+
+    def __init__(self, args):
+        self.output_dir, self.output_format = args.output_dir, args.output_format
+
+
+def _finish_in_worker(spec, T, fn, bases, a1, a2, qc):
+    """Worker-process side of the merge: calls of one read + its original bases -> revised read -> its output file
+    (the 0.5 ms of NumPy, string building and file IO per read that the main process' finisher thread used to spend
+    under the GIL).  qc: per-window Phred characters (FASTQ) or None (FASTA).  Returns (bases written, error)."""
+    try:
+        codes = np.frombuffer(np.asarray(bases, dtype="S1").tobytes(), dtype=np.uint8)
+        off, n = (T - 1) // 2, len(a1)
+        if n == 0:
+            seq, qual = codes.tobytes().decode("ascii"), "#" * len(codes)
+        else:
+            first, second, count = hs.merge_calls(codes[off:off + n], a1, a2)
+            z = qc if qc is not None else np.zeros(n, np.uint8)
+            seq_mid, q_mid = hs.expand_calls(first, second, count, z, z)
+            seq = (codes[:off].tobytes() + seq_mid.tobytes() + codes[off + n:].tobytes()).decode("ascii")
+            qual = None
+            if qc is not None:
+                edge = np.full(1, ord("#"), np.uint8)
+                qual = (np.repeat(edge, off).tobytes() + q_mid.tobytes()
+                        + np.repeat(edge, len(codes) - off - n).tobytes()).decode("ascii")
+        write_read(spec, fn, seq, qual)
+        return len(seq), None
+    except Exception as e:
+        return 0, repr(e)
+
+
 def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
     os.makedirs(args.output_dir, exist_ok=True)
     if args.output_format == "fastq":
@@ -305,22 +337,25 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     kBatchEvents = 8 * max(int(getattr(args, "batch", 4096)), 1024)
     per_task = max(1, min(16, kBatchEvents // 6500))
 
+    pool = None
+    if nworkers > 1 and len(files) >= 4:
+        import multiprocessing as mp
+        pool = ProcessPoolExecutor(nworkers, mp_context=mp.get_context("spawn"))
+
     def results():
         """Yields (entries, bundle): `_load_one` tuples, and for pooled tasks their pre-concatenated raw reads."""
-        if nworkers == 1 or len(files) < 4:
+        if pool is None:
             for j in jobs:
                 yield [_load_one(j)], None
             return
-        import multiprocessing as mp
         from collections import deque
-        with ProcessPoolExecutor(nworkers, mp_context=mp.get_context("spawn")) as pool:
-            pend = deque()
-            for k in range(0, len(jobs), per_task):
-                pend.append(pool.submit(_load_bundle, jobs[k:k + per_task]))
-                if len(pend) >= 3 * nworkers:
-                    yield pend.popleft().result()
-            while pend:
+        pend = deque()
+        for k in range(0, len(jobs), per_task):
+            pend.append(pool.submit(_load_bundle, jobs[k:k + per_task]))
+            if len(pend) >= 3 * nworkers:
                 yield pend.popleft().result()
+        while pend:
+            yield pend.popleft().result()
 
     def fallback(fn, rt, fq, e):                      # NanoReviser.py:146-152 / :173-179
         stats["failed"].append(fn)
@@ -338,24 +373,50 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
 
     want_qual = args.output_format == "fastq"
 
+    spec = _OutSpec(args)
+    finishing = []                                    # (future, fn, rt, fq) of merges handed to the pool
+
+    def finished(fn, nb):
+        stats["bases"] += nb
+        if not args.test_mode:
+            log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved......")
+        else:
+            log("INFO Congratulations, NanoReviser is installed properly")
+        note(fn, True)
+
     def finish_batch(batch, calls):
-        """Finisher thread: merge + write per read (NumPy + file IO; overlaps the next device call)."""
+        """Finisher thread.  With a worker pool the merge + file write of each read is a pool task (the calls and
+        the original bases are ~20 KB per read); without one it happens here."""
         reviser = box["rv"]
         for (fn, rt, fq), c in zip(batch, calls):
             if isinstance(c, Exception):
                 fallback(fn, rt, fq, c)
                 continue
             try:
+                if pool is not None:
+                    p1, p2, a1, a2 = c
+                    qc = phred_chars(p1, p2, a1, a2) if want_qual and len(a1) else None
+                    finishing.append((pool.submit(_finish_in_worker, spec, reviser.T, fn, np.asarray(rt.bases),
+                                                  np.asarray(a1), np.asarray(a2), qc), fn, rt, fq))
+                    continue
                 seq, qual = _finish_read(reviser.T, rt, *c, want_qual=want_qual)
                 write_read(args, fn, seq, qual)
-                stats["bases"] += len(seq)
-                if not args.test_mode:
-                    log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved......")
-                else:
-                    log("INFO Congratulations, NanoReviser is installed properly")
-                note(fn, True)
+                finished(fn, len(seq))
             except Exception as e:
                 fallback(fn, rt, fq, e)
+
+    def collect_finished(block):
+        """Results of the pooled merges (main thread)."""
+        while finishing and (block or finishing[0][0].done()):
+            fut, fn, rt, fq = finishing.pop(0)
+            try:
+                nb, err = fut.result()
+            except Exception as e:                    # the pool broke (a parser process died)
+                nb, err = 0, repr(e)
+            if err is None:
+                finished(fn, nb)
+            else:
+                fallback(fn, rt, fq, err)
 
     def run_batch(batch, packed=None, bundle=None):
         """Engine thread: one device call for the batch; merging and writing go to the finisher."""
@@ -387,7 +448,12 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     from concurrent.futures import ThreadPoolExecutor
     from collections import deque
     inflight = deque()
-    with ThreadPoolExecutor(1) as eng, ThreadPoolExecutor(1) as fin:
+    import contextlib
+    with contextlib.ExitStack() as stack:
+        if pool is not None:                          # whatever happens below, the parser pool does not outlive us
+            stack.callback(lambda: pool.shutdown(wait=False, cancel_futures=True))
+        eng = stack.enter_context(ThreadPoolExecutor(1))
+        fin = stack.enter_context(ThreadPoolExecutor(1))
         created = eng.submit(lambda: box.__setitem__("rv", reviser())) if lazy else None
 
         def submit(batch, bundle=None):
@@ -436,11 +502,13 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             if bundled:
                 inflight.append(submit(bundled, bundle))
                 drain(2)
+            collect_finished(False)
         if batch:
             inflight.append(submit(batch))
         drain(0)
         if created is not None:
             created.result()
+        collect_finished(True)
     reviser = box["rv"]
     sat = getattr(reviser, "saturated", None)
     if callable(sat):                                 # f16x2 range guard: stages re-run on the f32 kernels
