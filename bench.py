@@ -788,7 +788,7 @@ def main(argv=None):
     ap.add_argument("--share-device", action="store_true",
                     help="rank r runs on device r %% device_count (rehearse N ranks on fewer GPUs; never the default)")
     ap.add_argument("--no-cli-e2e", action="store_true", help="skip host_inclusive.cli_e2e (the CLI in a child process)")
-    ap.add_argument("--cli-reps", type=int, default=1000, help="cli_e2e: copies of each committed fixture read")
+    ap.add_argument("--cli-reps", type=int, default=2000, help="cli_e2e: copies of each committed fixture read")
     ap.add_argument("--cli-threads", type=int, default=16, help=argparse.SUPPRESS)
     ap.add_argument("--cli-e2e-helper", action="store_true", help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
