@@ -550,6 +550,10 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
                                            "flop_per_window": flop_per_window(T)}
     out["kernel_us" + suffix] = kernel_us
     out["kernel_us_sum" + suffix] = sum(kernel_us.values())
+    if precision == "f16x2":
+        out["kernel_us_note" + suffix] = ("bracketed figures (each contains one empty bracket, roofline.empty_bracket_us); f16x2: "
+                                          "the 6->16 Bi-LSTM runs as four extra waves of the signal-branch launch "
+                                          "(cnn_r_kernel), so its own slot shows only the empty bracket")
     return out
 
 

@@ -1085,6 +1085,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   };
   int rc;
 
+  bool h2_fused_l1 = false;          // f16x2 mode: the 6 -> 16 Bi-LSTM ran inside the signal-branch launch
   // 0: signal branch.  (Running it on a second stream beside lstm1/lstm2 was measured: the
   // dispatcher serialises the two launches anyway - each fills the LDS/register file of every CU -
   // and the event fork/join costs ~20 us per group, so everything stays on one stream.)
@@ -1127,9 +1128,18 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         a2.k[m] = d.cr_k;
       }
       a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
-      // persistent, one workgroup of eight waves per CU and model; a wave takes 16-event units round-robin
+      // the 6 -> 16 Bi-LSTM of this group rides along as four more waves per workgroup (nrv_cnn_r.h)
+      a2.l1_T = T; a2.l1_rows = n;
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        a2.l1[m] = Lstm1ModelParams{d.all + d.l1w16, d.all + d.l1b16, d.all + d.l1s2, d.all + d.l1h2, d_feat,
+                                    read_mode ? 1 : 0, h->X1[m]};
+      }
+      // persistent, one workgroup of eight + four waves per CU and model; a conv wave takes 16-event units round-robin
       const int wg = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves;
-      hipLaunchKernelGGL(cnn_r_kernel, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
+      if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
+      else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
+      h2_fused_l1 = true;
     } else {
       CnnArgs a;
       for (int m = 0; m < 2; ++m) {
@@ -1157,7 +1167,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       launch_lstm<0, 0, 16, true>(h, a, tiles, h->geo[0]);
     } else
 #endif
-    {                                            // the dedicated 16x16x4 kernel (f32 in every mode)
+    if (!h2_fused_l1) {                          // the dedicated 16x16x4 kernel (f32 in every mode)
       Lstm1Args a1;
       a1.T = T; a1.n_rows = n;
       for (int m = 0; m < 2; ++m) {

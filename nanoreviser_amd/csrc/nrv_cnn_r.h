@@ -3,6 +3,7 @@
 #pragma once
 #include "nrv_common.h"
 #include "nrv_lstm_f16x2s.h"   // f16x8, mfma16_f16
+#include "nrv_lstm1.h"         // lstm1_unit: the 6 -> 16 Bi-LSTM rides along as four more waves
 
 namespace nrv {
 
@@ -30,7 +31,14 @@ namespace nrv {
 //           split-plane row (instead of 16 two-byte stores), behind the range guard (nrv_cnn_f16x2.h).
 // Each conv1 position is computed by two quarters (the price of keeping everything in registers: 2 x 40 VALU per
 // pair); per 16-event unit a wave issues ~2300 vector instructions, 231 MFMAs, 104 + ~100 LDS reads.
-// A wave owns whole units, eight waves per workgroup (two per SIMD), persistent: one workgroup per CU and model.
+// A wave owns whole units, eight such waves per workgroup (two per SIMD), persistent: one workgroup per CU and model.
+//
+// FOUR MORE WAVES per workgroup run the first read-branch layer, Bi-LSTM(6 -> 16) (lstm1_unit, nrv_lstm1.h: one wave
+// = 16 rows of one direction, f32 16x16x4 tiles, weights in registers, wave-private).  That layer is independent of
+// the signal branch until the 192 -> 128 layer, is a 13 us launch of 1024 latency-bound waves on its own - one per
+// SIMD - and needs 96 registers and 1 KB of LDS per wave: beside two conv waves of <= 168 registers it fits the SIMD,
+// its dependent chain runs in their shadow, and the launch is gone.  (As a second STREAM the same overlap cost ~20 us
+// of event fork / join in round 2; as a role of this launch it costs nothing.)
 // ---------------------------------------------------------------------------------------
 struct CnnRConsts {        // per model, BY VALUE in the kernel arguments: scalar loads
   float w1[24];            // first convolution [tap][co]
@@ -50,6 +58,8 @@ struct CnnRArgs {
   const float* signal;     // [n][T][50] (window mode) or [N][50] (event mode)
   int T, n_rows, n_tiles;  // as CnnH2Args: 32-event tiles
   unsigned* sat;           // range guard counter
+  Lstm1ModelParams l1[2];  // the 6 -> 16 Bi-LSTM of the same launch group (rows = windows)
+  int l1_T, l1_rows;
 };
 
 #ifndef NRV_CNNR_PK
@@ -61,7 +71,9 @@ struct CnnRArgs {
 #ifndef NRV_CNNR_WAVES
 #define NRV_CNNR_WAVES 8
 #endif
-constexpr int kCnnRWaves = NRV_CNNR_WAVES, kCnnRThreads = 64 * kCnnRWaves;
+constexpr int kCnnRWaves = NRV_CNNR_WAVES;             // conv / dense waves
+constexpr int kCnnRL1Waves = 4;                         // 6 -> 16 Bi-LSTM waves
+constexpr int kCnnRThreads = 64 * (kCnnRWaves + kCnnRL1Waves);
 constexpr float kCnnRImgScale = 64.0f;                  // 2^6
 constexpr float kCnnRDenseDescale = 1.0f / 1024.0f;     // 2^-10
 
@@ -70,15 +82,17 @@ typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f32r;
 
-// Wave-private ring of conv1 results: 11 position slots (9 are live at any time), one all-zero slot (the second
+// Wave-private ring of conv1 results: 10 position slots (9 are live at any time), one all-zero slot (the second
 // convolution's zero padding) and one write-only slot for positions past the window (so that the conv1 code has
 // no branch and stays in one basic block with the MFMAs it is interleaved with); each [term 2][event 16][8 f16] = 512 B.
-constexpr int kCnnRRing = 11, kCnnRSlot = 2 * 16 * 8, kCnnRC1Wave = (kCnnRRing + 2) * kCnnRSlot;   // f16
+constexpr int kCnnRRing = 10, kCnnRSlot = 2 * 16 * 8, kCnnRC1Wave = (kCnnRRing + 2) * kCnnRSlot;   // f16
 
+template <int ACT>
 __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args) {
   constexpr int NKS = 13;
   __shared__ __attribute__((aligned(16))) float wd_s[NKS * 4 * 2 * 256];            // 104 KiB
-  __shared__ __attribute__((aligned(16))) _Float16 c1_s[kCnnRWaves * kCnnRC1Wave];  // 6.5 KiB per wave
+  __shared__ __attribute__((aligned(16))) _Float16 c1_s[kCnnRWaves * kCnnRC1Wave];  // 6 KiB per wave
+  __shared__ __attribute__((aligned(16))) float l1h_s[kCnnRL1Waves][16 * 16 + 16];  // lstm1_unit's wave-private images
   const CnnRModelParams& P = args.m[blockIdx.y];
   const CnnRConsts& K = args.k[blockIdx.y];
   const int T = args.T;
@@ -100,6 +114,14 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
   }
   __syncthreads();                                   // the only barrier: from here on the waves are independent
 
+  if (wave >= kCnnRWaves) {
+    // ================================ 6 -> 16 Bi-LSTM role ====================================
+    const int nu = 2 * ((args.l1_rows + 15) / 16);   // units: (16-row block, direction)
+    for (int idx = blockIdx.x * kCnnRL1Waves + (wave - kCnnRWaves); idx < nu; idx += gridDim.x * kCnnRL1Waves)
+      lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, idx & 1, idx >> 1, lane, l1h_s[wave - kCnnRWaves]);
+    return;
+  }
+
   typedef __attribute__((address_space(3))) _Float16 lds_h;
   typedef __attribute__((address_space(3))) f16x8 lds_h8;
   lds_h* const c1 = (lds_h*)c1_s + wave * kCnnRC1Wave;
@@ -114,18 +136,14 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
   for (int mt = 0; mt < 4; ++mt) dbias[mt] = *(const f32x4*)(P.dbias + 16 * mt + 4 * q);
   const float* wd = wd_s + lane * 4;
   bool bad = false;
-  // The first convolution's 48 constants, in VECTOR registers for the whole launch.  As kernel arguments (SGPRs) they
-  // do not fit beside the loop's other scalars: hipcc re-loaded them with three s_load_dwordx16 in EVERY k-step, and the
-  // conv1 code waited for the scalar cache each time.  The opaque copy keeps the values from being re-materialised.
-  float w1v[24], b1v[8], s1v[8], h1v[8];
-#pragma unroll
-  for (int i = 0; i < 24; ++i) { w1v[i] = K.w1[i]; asm volatile("" : "+v"(w1v[i])); }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    b1v[i] = K.b1[i]; s1v[i] = K.s1[i]; h1v[i] = K.h1[i];
-    asm volatile("" : "+v"(b1v[i]), "+v"(s1v[i]), "+v"(h1v[i]));
-  }
-  // ring slot of position pos: pos % 12 inside the window, the zero slot outside; this lane's event row inside the slot
+  // The first convolution's 48 constants are kernel arguments (scalar loads).  They do not stay in SGPRs through the
+  // k-step loop (hipcc re-loads them with three s_load_dwordx16 per k-step); holding them in 48 VGPRs instead was
+  // built and measured: the same time, and twelve waves per workgroup leave no room for it (<= 168 registers).
+#define w1v K.w1
+#define b1v K.b1
+#define s1v K.s1
+#define h1v K.h1
+  // ring slot of position pos: pos % 10 inside the window, the zero slot outside; this lane's event row inside the slot
   auto slot_of = [&](int pos) __attribute__((always_inline)) {
     return ((pos >= 0 && pos < kSig) ? (pos % kCnnRRing) : kCnnRRing) * kCnnRSlot + n * 8;
   };
@@ -328,5 +346,10 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
   }
   if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(args.sat, 1u);
 }
+
+#undef w1v
+#undef b1v
+#undef s1v
+#undef h1v
 
 }  // namespace nrv

@@ -31,17 +31,12 @@ struct Lstm1Args {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int ACT, bool OUT_SPLIT = false>
-__global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
-  __shared__ __attribute__((aligned(16))) float hbuf[4][16 * 16 + 16];
-  const Lstm1ModelParams& P = args.m[blockIdx.z];
-  const int T = args.T, dir = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wave's unit: 16 rows (block rb) of one direction.  hb: 272 floats of wave-private LDS.
+template <int ACT, bool OUT_SPLIT>
+__device__ __forceinline__ void lstm1_unit(const Lstm1ModelParams& P, const int T, const int n_rows, const int dir,
+                                           const int rb, const int lane, float* hb) {
   const int q = lane >> 4, c = lane & 15;
-  const int rb = blockIdx.x * 4 + wave;                  // 16-row block of this wave
   const int row = rb * 16 + c;                           // the row this lane feeds as A operand
-  float* hb = hbuf[wave];
-
   // weights of this direction, register-resident
   float win[2][4], wrec[4][4], bias[4];
   {
@@ -62,7 +57,7 @@ __global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
 
   auto load_x = [&](int t, float& x0, float& x1) {
     x0 = 0.f; x1 = 0.f;
-    if (row < args.n_rows) {
+    if (row < n_rows) {
       const float* src = P.plain_in +
           (P.plain_ev_stride ? (size_t)(row + t) * kFeat : ((size_t)row * T + t) * kFeat);
       x0 = src[q];                                       // k = q        (k-step 0)
@@ -131,6 +126,13 @@ __global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
     }
     x0 = nx0; x1 = nx1;
   }
+}
+
+template <int ACT, bool OUT_SPLIT = false>
+__global__ void __launch_bounds__(256) lstm1_kernel(const Lstm1Args args) {
+  __shared__ __attribute__((aligned(16))) float hbuf[4][16 * 16 + 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  lstm1_unit<ACT, OUT_SPLIT>(args.m[blockIdx.z], args.T, args.n_rows, blockIdx.y, blockIdx.x * 4 + wave, lane, hbuf[wave]);
 }
 
 
