@@ -63,6 +63,9 @@ static bool make_blob(const nrv_weights* w, int T, int C, Blob* b) {
 // HOST optimiser, which would fully unroll the constant-bound packing loops below (an 11-minute
 // host compile).  Every loop of the packing code therefore carries an explicit "do not unroll" - the code
 // is still optimised otherwise (round 2 had the optimiser off altogether: 0.12 s of packing per nrv_create).
+#ifndef NRV_FRONT
+#define NRV_FRONT 0
+#endif
 #define NRV_HOST_COLD __attribute__((noinline))
 #define NRV_FOR _Pragma("clang loop unroll(disable)") for
 // One packed k-group for one 32-column tile: dst[lane][j] = get(k = 8*kg + 4*(lane>>5) + j, lane&31)
@@ -1085,6 +1088,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   };
   int rc;
 
+  bool h2_fused_l2 = false;          // ... and the 32 -> 64 Bi-LSTM too (NRV_FRONT)
   bool h2_fused_l1 = false;          // f16x2 mode: the 6 -> 16 Bi-LSTM ran inside the signal-branch launch
   // 0: signal branch.  (Running it on a second stream beside lstm1/lstm2 was measured: the
   // dispatcher serialises the two launches anyway - each fills the LDS/register file of every CU -
@@ -1136,8 +1140,24 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                     read_mode ? 1 : 0, h->X1[m]};
       }
       // persistent, one workgroup of eight + four waves per CU and model; a conv wave takes 16-event units round-robin
+#if NRV_FRONT
+      // the whole front in one launch: four conv waves + four read-branch waves (6 -> 16 twice, then 32 -> 64)
+      for (int m = 0; m < 2; ++m) {
+        const DevModel& d = h->dm[m];
+        a2.l2[m] = Lstm2TModelParams{d.all + d.l2t_w, d.all + d.l2t_b, h->X1[m], h->X2[m], d.descale[1]};
+      }
+      {
+        const int wgc = (2 * n_tiles + kFrontConvWaves - 1) / kFrontConvWaves, wgr = 2 * ((n + 63) / 64);
+        int gx = wgc > wgr ? wgc : wgr;
+        gx = gx < 128 ? (gx + 1) & ~1 : 128;
+        if (h->act == 0) hipLaunchKernelGGL((cnn_r_kernel<0, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);
+        else hipLaunchKernelGGL((cnn_r_kernel<1, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);
+        h2_fused_l1 = h2_fused_l2 = true;
+      }
+#endif
       const int wg = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves;
-      if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
+      if (h2_fused_l2) {}
+      else if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
       else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
       h2_fused_l1 = true;
     } else {
@@ -1195,7 +1215,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
 #else
     constexpr bool l2t = true;
 #endif
-    if (h->h2 && l2t) {
+    if (h2_fused_l2) {}
+    else if (h->h2 && l2t) {
       // wave-private transposed kernel; hands over h x 2^13 (BatchNorm(128) is in the 192->128 layer's weights)
       Lstm2TArgs ta;
       ta.T = T; ta.n_rows = n;

@@ -4,6 +4,7 @@
 #include "nrv_common.h"
 #include "nrv_lstm_f16x2s.h"   // f16x8, mfma16_f16
 #include "nrv_lstm1.h"         // lstm1_unit: the 6 -> 16 Bi-LSTM rides along as four more waves
+#include "nrv_lstm2_t.h"       // lstm2_t_unit: ... and, in the FRONT form, the 32 -> 64 Bi-LSTM behind it
 
 namespace nrv {
 
@@ -60,10 +61,11 @@ struct CnnRArgs {
   unsigned* sat;           // range guard counter
   Lstm1ModelParams l1[2];  // the 6 -> 16 Bi-LSTM of the same launch group (rows = windows)
   int l1_T, l1_rows;
+  Lstm2TModelParams l2[2]; // FRONT form: the 32 -> 64 Bi-LSTM behind it
 };
 
-#ifndef NRV_CNNR_PK
-#define NRV_CNNR_PK 0
+#ifndef NRV_FEXP
+#define NRV_FEXP 0                                   // timing experiments on the FRONT form: 1 no read branch, 2 no 6 -> 16, 4 no conv units
 #endif
 #ifndef NRV_CNNR_SGB
 #define NRV_CNNR_SGB 1
@@ -82,16 +84,27 @@ typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f32r;
 
-// Wave-private ring of conv1 results: 10 position slots (9 are live at any time), one all-zero slot (the second
-// convolution's zero padding) and one write-only slot for positions past the window (so that the conv1 code has
-// no branch and stays in one basic block with the MFMAs it is interleaved with); each [term 2][event 16][8 f16] = 512 B.
-constexpr int kCnnRRing = 10, kCnnRSlot = 2 * 16 * 8, kCnnRC1Wave = (kCnnRRing + 2) * kCnnRSlot;   // f16
+// Wave-private ring of conv1 results: 12 position slots (9 are live at any time; 12 so that a quarter's four
+// positions wrap in two of the six slot bases only), each [term 2][event 16][8 f16] = 512 B; behind the rings one
+// all-zero slot (the second convolution's zero padding) and one write-only slot for positions past the window (so that
+// the conv1 code has no branch and stays in one basic block with the MFMAs it is interleaved with), shared by all waves.
+constexpr int kCnnRRing = 12, kCnnRSlot = 2 * 16 * 8, kCnnRC1Wave = kCnnRRing * kCnnRSlot;   // f16
 
-template <int ACT>
-__global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args) {
+// FRONT = true: the whole front of the network in one launch.  Four conv / dense waves (their dense fragments come
+// from L2, one k-step ahead, instead of LDS) and four READ-BRANCH waves per workgroup, each of which runs, for its
+// 16 windows, the 6 -> 16 layer in both directions and then one direction (blockIdx.x & 1) of the 32 -> 64 layer
+// (lstm2_t_unit, whose 112 KB of weights and bias image take the LDS the dense fragments had).  The 6 -> 16 layer is
+// computed twice (once per direction workgroup; identical values to identical addresses): that is what lets X1 stay
+// inside the wave - no dependency between workgroups.
+constexpr int kFrontConvWaves = 4, kFrontThreads = 64 * (kFrontConvWaves + kCnnRL1Waves);
+template <int ACT, bool FRONT = false>
+__global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_kernel(const CnnRArgs args) {
   constexpr int NKS = 13;
-  __shared__ __attribute__((aligned(16))) float wd_s[NKS * 4 * 2 * 256];            // 104 KiB
-  __shared__ __attribute__((aligned(16))) _Float16 c1_s[kCnnRWaves * kCnnRC1Wave];  // 6 KiB per wave
+  constexpr int kCnnRWaves = FRONT ? kFrontConvWaves : nrv::kCnnRWaves;
+  constexpr int kCnnRThreads = FRONT ? kFrontThreads : nrv::kCnnRThreads;
+  // dense fragments (104 KiB), or the 32 -> 64 layer's weights (96 KiB) + bias image (16 KiB)
+  __shared__ __attribute__((aligned(16))) float wd_s[FRONT ? kL2tWFrags * 256 + 16 * 256 : NKS * 4 * 2 * 256];
+  __shared__ __attribute__((aligned(16))) _Float16 c1_s[kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot];  // 6 KiB per wave + 1
   __shared__ __attribute__((aligned(16))) float l1h_s[kCnnRL1Waves][16 * 16 + 16];  // lstm1_unit's wave-private images
   const CnnRModelParams& P = args.m[blockIdx.y];
   const CnnRConsts& K = args.k[blockIdx.y];
@@ -100,8 +113,11 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, q = lane >> 4;
 
-  {
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.dfrag, NKS * 8 * 1024);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.dfrag, NKS * 8 * 1024);
+  if constexpr (FRONT) {
+    lstm2_t_stage(args.l2[blockIdx.y], blockIdx.x & 1, wd_s, wd_s + kL2tWFrags * 256, threadIdx.x, kCnnRThreads);
+    for (int i = threadIdx.x; i < kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot; i += kCnnRThreads) c1_s[i] = (_Float16)0.f;
+  } else {
     for (int base = 0; base < NKS * 8 * 64; base += 8 * kCnnRThreads) {
       f32x4 v[8];
 #pragma unroll
@@ -110,12 +126,29 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
       for (int j = 0; j < 8; ++j)
         if (base + j * kCnnRThreads + threadIdx.x < NKS * 8 * 64) ((f32x4*)wd_s)[base + j * kCnnRThreads + threadIdx.x] = v[j];
     }
-    for (int i = threadIdx.x; i < kCnnRWaves * kCnnRC1Wave; i += kCnnRThreads) c1_s[i] = (_Float16)0.f;   // incl. the zero slots
+    for (int i = threadIdx.x; i < kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot; i += kCnnRThreads) c1_s[i] = (_Float16)0.f;   // incl. the zero slot
   }
   __syncthreads();                                   // the only barrier: from here on the waves are independent
 
   if (wave >= kCnnRWaves) {
     // ================================ 6 -> 16 Bi-LSTM role ====================================
+    if constexpr (FRONT) {
+      // ======================= whole read branch: 6 -> 16 both directions, then 32 -> 64 ====================
+      const int nrb = (args.l1_rows + 15) / 16, rw = wave - kCnnRWaves;
+      for (int rb = (blockIdx.x >> 1) * kCnnRL1Waves + rw; rb < ((NRV_FEXP & 1) ? 0 : nrb); rb += (gridDim.x >> 1) * kCnnRL1Waves) {
+#if NRV_FEXP & 2                                     // 2: no 6 -> 16 layer in the chain
+        if (rb < 0)
+#endif
+        lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, 0, rb, lane, l1h_s[rw]);
+#if NRV_FEXP & 2
+        if (rb < 0)
+#endif
+        lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, 1, rb, lane, l1h_s[rw]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X1 of these 16 windows is in L2; this wave reads it back
+        lstm2_t_unit<ACT, true>(args.l2[blockIdx.y], args.l1_T, blockIdx.x & 1, rb, lane, wd_s, wd_s + kL2tWFrags * 256);
+      }
+      return;
+    }
     const int nu = 2 * ((args.l1_rows + 15) / 16);   // units: (16-row block, direction)
     for (int idx = blockIdx.x * kCnnRL1Waves + (wave - kCnnRWaves); idx < nu; idx += gridDim.x * kCnnRL1Waves)
       lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, idx & 1, idx >> 1, lane, l1h_s[wave - kCnnRWaves]);
@@ -143,87 +176,81 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
 #define b1v K.b1
 #define s1v K.s1
 #define h1v K.h1
-  // ring slot of position pos: pos % 10 inside the window, the zero slot outside; this lane's event row inside the slot
-  auto slot_of = [&](int pos) __attribute__((always_inline)) {
-    return ((pos >= 0 && pos < kSig) ? (pos % kCnnRRing) : kCnnRRing) * kCnnRSlot + n * 8;
+  // Ring slot of position pos: pos % 12.  A quarter's positions C + q never wrap for C % 12 <= 8, so the slot is an
+  // immediate offset on ONE per-lane address (rq); the two bases that can wrap (C % 12 = 9, 11) have their own.
+  lds_h* const rq = c1 + q * kCnnRSlot + n * 8;
+  lds_h* const rq9 = c1 + ((9 + q) % kCnnRRing) * kCnnRSlot + n * 8;
+  lds_h* const rq11 = c1 + ((11 + q) % kCnnRRing) * kCnnRSlot + n * 8;
+  lds_h* const zslot = (lds_h*)c1_s + kCnnRWaves * kCnnRC1Wave + n * 8;     // all-zero slot, then the write-only one
+  auto slot_c = [&](int C) __attribute__((always_inline)) {       // slot of position C + q (C a compile-time constant)
+    const int cm = ((C % kCnnRRing) + kCnnRRing) % kCnnRRing;
+    return cm == 9 ? rq9 : cm == 11 ? rq11 : rq + cm * kCnnRSlot;
   };
 
-#if NRV_EXP & 1                                      // timing experiments (results wrong): 1 no units at all
+#if (NRV_EXP & 1) || (NRV_FEXP & 4)                  // timing experiments (results wrong): 1 no units at all
   const int n_units = 0;
 #else
   const int n_units = 2 * args.n_tiles;
 #endif
-  // units of 16 events: unit u = 2 * tile + sub, dealt round-robin over all waves of the launch's workgroups
-  // conv1 + BatchNorm of position pos (this lane's event) from its three samples -> ring slot, both terms.
-  // (NRV_CNNR_PK=1 writes the channel pairs as packed f32 math, v_pk_fma_f32: measured SLOWER, 73 vs 67 us.)
-  auto conv1_store = [&](int pos, float xm, float xc, float xp) __attribute__((always_inline)) {
-    {
-#if NRV_CNNR_PK
-      const f32x2r xm2 = {xm, xm}, xc2 = {xc, xc}, xp2 = {xp, xp};
-      f16x8 hi, lo;
+  // conv1 + BatchNorm of one position (this lane's event) from its three samples -> ring slot d, both terms.
+  // (Written as packed f32 math, v_pk_fma_f32, it was measured SLOWER, 73 vs 67 us.)
+  auto conv1_store = [&](lds_h* d, float xm, float xc, float xp) __attribute__((always_inline)) {
+    float c[8];
 #pragma unroll
-      for (int o = 0; o < 8; o += 2) {
-        f32x2r tt = {b1v[o], b1v[o + 1]};
-        tt = __builtin_elementwise_fma(xm2, f32x2r{w1v[0 * 8 + o], w1v[0 * 8 + o + 1]}, tt);
-        tt = __builtin_elementwise_fma(xc2, f32x2r{w1v[1 * 8 + o], w1v[1 * 8 + o + 1]}, tt);
-        tt = __builtin_elementwise_fma(xp2, f32x2r{w1v[2 * 8 + o], w1v[2 * 8 + o + 1]}, tt);
-        tt = __builtin_elementwise_max(tt, f32x2r{0.f, 0.f});
-        tt = __builtin_elementwise_fma(tt, f32x2r{s1v[o], s1v[o + 1]}, f32x2r{h1v[o], h1v[o + 1]});
-        const f16x2r hp = __builtin_convertvector(tt, f16x2r);
-        hi[o] = hp[0]; hi[o + 1] = hp[1];
-        const f16x2r lp = __builtin_convertvector(tt - __builtin_convertvector(hp, f32x2r), f16x2r);
-        lo[o] = lp[0]; lo[o + 1] = lp[1];
-      }
-#else
-      float c[8];
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        float tt = b1v[o];
-        tt = __builtin_fmaf(xm, w1v[0 * 8 + o], tt);
-        tt = __builtin_fmaf(xc, w1v[1 * 8 + o], tt);
-        tt = __builtin_fmaf(xp, w1v[2 * 8 + o], tt);
-        tt = __builtin_fmaxf(tt, 0.f);
-        c[o] = __builtin_fmaf(tt, s1v[o], h1v[o]);
-      }
-      f16x8 hi, lo;
-#pragma unroll
-      for (int o = 0; o < 8; o += 2) {
-        const f16x2r hp = __builtin_convertvector(f32x2r{c[o], c[o + 1]}, f16x2r);
-        hi[o] = hp[0]; hi[o + 1] = hp[1];
-        const f16x2r lp = __builtin_convertvector(f32x2r{c[o] - (float)hp[0], c[o + 1] - (float)hp[1]}, f16x2r);
-        lo[o] = lp[0]; lo[o + 1] = lp[1];
-      }
-#endif
-      lds_h* d = c1 + (pos < kSig ? pos % kCnnRRing : kCnnRRing + 1) * kCnnRSlot + n * 8;
-      *(lds_h8*)d = hi;
-      *(lds_h8*)(d + 16 * 8) = lo;
+    for (int o = 0; o < 8; ++o) {
+      float tt = b1v[o];
+      tt = __builtin_fmaf(xm, w1v[0 * 8 + o], tt);
+      tt = __builtin_fmaf(xc, w1v[1 * 8 + o], tt);
+      tt = __builtin_fmaf(xp, w1v[2 * 8 + o], tt);
+      tt = __builtin_fmaxf(tt, 0.f);
+      c[o] = __builtin_fmaf(tt, s1v[o], h1v[o]);
     }
+    f16x8 hi, lo;
+#pragma unroll
+    for (int o = 0; o < 8; o += 2) {
+      const f16x2r hp = __builtin_convertvector(f32x2r{c[o], c[o + 1]}, f16x2r);
+      hi[o] = hp[0]; hi[o + 1] = hp[1];
+      const f16x2r lp = __builtin_convertvector(f32x2r{c[o] - (float)hp[0], c[o + 1] - (float)hp[1]}, f16x2r);
+      lo[o] = lp[0]; lo[o + 1] = lp[1];
+    }
+    *(lds_h8*)d = hi;
+    *(lds_h8*)(d + 16 * 8) = lo;
   };
 
+  // units of 16 events: unit u = 2 * tile + sub, dealt round-robin over all waves of the launch's workgroups
   for (int u = blockIdx.x * kCnnRWaves + wave; u < n_units; u += gridDim.x * kCnnRWaves) {
     const int b = u >> 1, sub = u & 1;
     const int wt = b / T, t = b % T;
     const int row = 16 * sub + n;
     const bool rok = wt * 32 + row < args.n_rows;
-    // this lane's event: samples straight from memory (200 B per event, L1-resident for the length of the unit)
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(args.signal + ((size_t)wt * 32 * T + t) * kSig, 0xffffffffu);
-    const unsigned xoff = rok ? (unsigned)(row * T * kSig) * 4u : 0u;
-    auto ldx = [&](int pos) __attribute__((always_inline)) {         // x[pos], zero outside the window / past the rows
-      const bool ok = rok && pos >= 0 && pos < kSig;
-      const float v = buf_load4(rs, xoff + (ok ? (unsigned)pos * 4u : 0u), 0);
-      return ok ? v : 0.f;
+    // This lane's event: samples straight from memory (200 B per event, L1-resident for the length of the unit).
+    // ONE per-lane address (+ one for the residual samples); the position is the instruction's immediate offset, and
+    // what lies outside the window or past the rows is addressed past the descriptor's end: the load returns 0.
+    const size_t ev0 = (size_t)wt * 32 * T + t, left = ((size_t)args.n_rows * T - ev0) * (kSig * 4);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(args.signal + ev0 * kSig, left < 0x7fffffffu ? (unsigned)left : 0x7fffffffu);
+    constexpr unsigned kOut = 0x80000000u;
+    const unsigned xq = rok ? (unsigned)(row * T * kSig + q) * 4u : kOut;          // position q
+    const unsigned xh = rok ? (unsigned)(row * T * kSig + (q >> 1)) * 4u : kOut;   // position q >> 1
+    // x[C + q] / x[C + (q >> 1)], C >= 0 a compile-time constant; the compare only where some quarter is outside
+    auto ldq = [&](int C) __attribute__((always_inline)) {
+      if (C >= kSig) return 0.f;
+      return buf_load4(rs, (C + 3 < kSig || q < kSig - C ? xq : kOut) + 4u * C, 0);
+    };
+    auto ldh = [&](int C) __attribute__((always_inline)) {
+      if (C >= kSig) return 0.f;
+      return buf_load4(rs, (C + 1 < kSig || (q >> 1) < kSig - C ? xh : kOut) + 4u * C, 0);
     };
     // prologue: conv1 of positions 0..3 (set 0), the samples of set 1 and the residual samples of k-step 0 in flight.
     // (Fetching the NEXT unit's first samples in this unit's last two k-steps, which load nothing useful, was built
     // and measured: 73 us instead of 65.)
     float xa[3], xres[2];
     {
-      const float x0 = ldx(q - 1), x1 = ldx(q), x2 = ldx(q + 1);
+      const float x0 = buf_load4(rs, rok && q > 0 ? xq - 4u : kOut, 0), x1 = ldq(0), x2 = ldq(1);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) xa[k] = ldx(4 + q - 1 + k);
+      for (int k = 0; k < 3; ++k) xa[k] = ldq(3 + k);
 #pragma unroll
-      for (int pi = 0; pi < 2; ++pi) xres[pi] = ldx(2 * pi + (q >> 1));
-      conv1_store(q, x0, x1, x2);
+      for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(2 * pi);
+      conv1_store(slot_c(0), x0, x1, x2);
     }
 
     f32x4 S[4];
@@ -249,7 +276,11 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
 #endif
       }
     };
-#pragma unroll 1
+    // The 13 k-steps are UNROLLED: every position is then a compile-time constant + q, so ring slots and sample
+    // addresses are immediate offsets, and the window-edge selects exist only in the four k-steps that touch an edge
+    // (0, 10, 11, 12).  As a rolled loop the same body spent ~60 of its ~200 vector instructions per k-step on
+    // pos % 10, range compares and selects.
+#pragma unroll
     for (int ks = 0; ks < ((NRV_EXP & 2) ? 1 : NKS); ++ks) {
       // The dense products of k-step ks - 1 go FIRST: they depend on nothing computed in this iteration, and the
       // conv1 arithmetic below is interleaved with them (one MFMA, three vector instructions, ...): measured with
@@ -257,22 +288,34 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
       dense();                                         // (k-step "-1": zero fragments)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {                 // this k-step's dense weights (used at the top of the next iteration)
-        wf[mt][1] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2 + 1) * 256);
-        wf[mt][0] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2) * 256);
+        if constexpr (FRONT) {
+          wf[mt][1] = buf_load16(wrs, (unsigned)lane * 16, (unsigned)(((ks * 4 + mt) * 2 + 1) * 1024));
+          wf[mt][0] = buf_load16(wrs, (unsigned)lane * 16, (unsigned)(((ks * 4 + mt) * 2) * 1024));
+        } else {
+          wf[mt][1] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2 + 1) * 256);
+          wf[mt][0] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2) * 256);
+        }
       }
       // conv1 of the NEXT set (positions 4 ks + 4 .. + 7; pair B below needs its first position), samples one step ahead
       const float xr0 = xres[0] * kCnnRImgScale, xr1 = xres[1] * kCnnRImgScale;
       {
         const float x0 = xa[0], x1 = xa[1], x2 = xa[2];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xa[k] = ldx(4 * (ks + 2) + q - 1 + k);
+        for (int k = 0; k < 3; ++k) xa[k] = ldq(4 * (ks + 2) - 1 + k);
+        if (ks + 1 < NKS) {
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi) xres[pi] = ldx(4 * (ks + 1) + 2 * pi + (q >> 1));
+          for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(4 * (ks + 1) + 2 * pi);
+        }
+        const int C = 4 * (ks + 1);                    // positions C + q; the last k-step's lie outside: nothing to do
+        if (C < kSig) {
+          lds_h* d = slot_c(C);
+          if (C + 3 >= kSig) d = q < kSig - C ? d : zslot + kCnnRSlot;
 #if !(NRV_EXP & 16)                                  // 16: no conv1 in the loop
-        conv1_store(4 * (ks + 1) + q, x0, x1, x2);
+          conv1_store(d, x0, x1, x2);
 #else
-        if (x0 + x1 + x2 == 1.2345f) conv1_store(4 * (ks + 1) + q, x0, x1, x2);
+          if (x0 + x1 + x2 == 1.2345f) conv1_store(d, x0, x1, x2);
 #endif
+        }
       }
 #if NRV_CNNR_SGB
 #pragma unroll
@@ -285,7 +328,10 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const int p = 4 * ks + 2 * pi;                 // this triple gives positions p, p + 1
-        const lds_h* src = c1 + slot_of(p + q - 1);    // B operand: k-group q = tap q, i.e. c1 at position p + q - 1
+        // B operand: k-group q = tap q, i.e. c1 at position p + q - 1 (zero padding outside the window)
+        const lds_h* src = slot_c(p - 1);
+        if (p - 1 < 0) src = q > 0 ? src : zslot;
+        if (p - 1 + 3 >= kSig) src = q < kSig - (p - 1) ? src : zslot;
         const f16x8 b_lo = *(const lds_h8*)(src + 16 * 8);
         const f16x8 b_hi = *(const lds_h8*)src;
         // ---- conv2: positions p (rows 0-7) and p + 1 (rows 8-15) of 16 events
@@ -300,17 +346,6 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
         // ---- bias is in, ReLU, BatchNorm, + sample (x 2^6), split: elements 4 pi .. 4 pi + 3 of the dense B fragment
         // (this lane: position p + (q >> 1); positions 50, 51 of the last k-step meet zero weights)
         const float xs = pi ? xr1 : xr0;
-#if NRV_CNNR_PK
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          f32x2r v = __builtin_elementwise_max(f32x2r{acc[r], acc[r + 1]}, f32x2r{0.f, 0.f});
-          v = __builtin_elementwise_fma(v, f32x2r{k1[r], k1[r + 1]}, f32x2r{k2[r], k2[r + 1]} + f32x2r{xs, xs});
-          const f16x2r hp = __builtin_convertvector(v, f16x2r);
-          fb_hi[4 * pi + r] = hp[0]; fb_hi[4 * pi + r + 1] = hp[1];
-          const f16x2r lp = __builtin_convertvector(v - __builtin_convertvector(hp, f32x2r), f16x2r);
-          fb_lo[4 * pi + r] = lp[0]; fb_lo[4 * pi + r + 1] = lp[1];
-        }
-#else
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(__builtin_fmaxf(acc[r], 0.f), k1[r], k2[r] + xs);
@@ -321,7 +356,6 @@ __global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args
           const f16x2r lp = __builtin_convertvector(f32x2r{v[r] - (float)hp[0], v[r + 1] - (float)hp[1]}, f16x2r);
           fb_lo[4 * pi + r] = lp[0]; fb_lo[4 * pi + r + 1] = lp[1];
         }
-#endif
       }
     }
     dense();                                           // the last k-step's products

@@ -54,38 +54,36 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int kL2tThreads = 256;
 constexpr int kL2tWFrags = 3 * 16 * 2;                 // 1 KiB fragments of one direction's weights
 
-template <int ACT>
-__global__ void __launch_bounds__(kL2tThreads) lstm2_t_kernel(const Lstm2TArgs args) {
 #ifndef NRV_L2T_NR
 #define NRV_L2T_NR 4
 #define NRV_L2T_LEAD 3
 #endif
+
+// Staging of one (direction, model)'s weights and bias image into LDS, by all `nthreads` threads of the workgroup
+// (the caller puts a barrier behind it).
+__device__ __forceinline__ void lstm2_t_stage(const Lstm2TModelParams& P, const int dir, float* wl, float* bl,
+                                              const int tid, const int nthreads) {
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc((const char*)P.wfrag + (size_t)dir * kL2tWFrags * 1024, kL2tWFrags * 1024);
+  for (int base = 0; base < kL2tWFrags * 64; base += 8 * nthreads) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = buf_load16(wrs, (unsigned)(base + j * nthreads + tid) * 16, 0);   // past the end: 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (base + j * nthreads + tid < kL2tWFrags * 64) ((f32x4*)wl)[base + j * nthreads + tid] = v[j];
+  }
+  const f32x4* bsrc = (const f32x4*)(P.bias + (size_t)dir * 16 * 256);
+  for (int i = tid; i < 16 * 64; i += nthreads) ((f32x4*)bl)[i] = bsrc[i];
+}
+
+// One wave's unit: the 16 rows of block rb, one direction, all T steps; wl / bl: the staged weights and bias image.
+template <int ACT, bool GLC>
+__device__ __forceinline__ void lstm2_t_unit(const Lstm2TModelParams& P, const int T, const int dir, const int rb,
+                                             const int lane, const float* wl, const float* bl) {
   constexpr int NR = NRV_L2T_NR, LEAD = NRV_L2T_LEAD;  // weight-pair ring: slots / pairs of lead
   static_assert(32 % NR == 0 && 16 % NR == 0 && LEAD < NR, "ring");
-  __shared__ __attribute__((aligned(16))) float wl[kL2tWFrags * 256];       // 96 KiB
-  __shared__ __attribute__((aligned(16))) float bl[16 * 256];               // 16 KiB
-  const Lstm2TModelParams& P = args.m[blockIdx.z];
-  const int T = args.T, dir = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, q = lane >> 4;
-  const int rb = blockIdx.x * 4 + wave;                // 16-row block of this wave
   const int tile = rb >> 1, trow = 16 * (rb & 1) + n;  // 32-row tile and this lane's row inside it
-
-  {
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc((const char*)P.wfrag + (size_t)dir * kL2tWFrags * 1024, kL2tWFrags * 1024);
-    for (int base = 0; base < kL2tWFrags * 64; base += 8 * kL2tThreads) {
-      f32x4 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = buf_load16(wrs, (unsigned)(base + j * kL2tThreads + threadIdx.x) * 16, 0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ((f32x4*)wl)[base + j * kL2tThreads + threadIdx.x] = v[j];
-    }
-    const f32x4* bsrc = (const f32x4*)(P.bias + (size_t)dir * 16 * 256);
-    for (int i = threadIdx.x; i < 16 * 64; i += kL2tThreads) ((f32x4*)bl)[i] = bsrc[i];
-  }
-  __syncthreads();                                     // the only barrier: from here on the waves are independent
-
   const float dsc = P.descale, dsc02 = 0.2f * dsc, dsc2 = 2.885390081777927f * dsc;
   // input fragment of timestep t: features 8 q .. + 7 of row trow (chunk 4 (q >> 1) + 2 term + (q & 1))
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(P.in + (size_t)tile * T * 8 * 128, (unsigned)T * 8 * 512);
@@ -95,8 +93,10 @@ __global__ void __launch_bounds__(kL2tThreads) lstm2_t_kernel(const Lstm2TArgs a
   auto load_x = [&](int s) __attribute__((always_inline)) {
     XFrag x;
     const unsigned so = (unsigned)t_of(s) * 8 * 512;
-    x.lo = buf_load16(xrs, xv + 1024, so);
-    x.hi = buf_load16(xrs, xv, so);
+    // GLC: when this wave produced X1 itself a moment ago (the fused launch), its loads must come from L2, not from a line
+    // the vector cache may hold
+    x.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xv + 1024, so, GLC ? 1 : 0));
+    x.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xv, so, GLC ? 1 : 0));
     return x;
   };
   // output: unit tile ut -> feature block dir * 4 + ut, this lane's units 4 q .. + 3 = 8 bytes at element 4 (q & 1) of
@@ -284,6 +284,18 @@ __global__ void __launch_bounds__(kL2tThreads) lstm2_t_kernel(const Lstm2TArgs a
       gates_plain(3, t);                               // the last step has no input projection to hide behind
     }
   }
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(kL2tThreads) lstm2_t_kernel(const Lstm2TArgs args) {
+  __shared__ __attribute__((aligned(16))) float wl[kL2tWFrags * 256];       // 96 KiB
+  __shared__ __attribute__((aligned(16))) float bl[16 * 256];               // 16 KiB
+  const Lstm2TModelParams& P = args.m[blockIdx.z];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lstm2_t_stage(P, blockIdx.y, wl, bl, threadIdx.x, kL2tThreads);
+  __syncthreads();                                     // the only barrier: from here on the waves are independent
+  lstm2_t_unit<ACT, false>(P, args.T, blockIdx.y, blockIdx.x * 4 + wave, lane, wl, bl);
 }
 
 }  // namespace nrv
