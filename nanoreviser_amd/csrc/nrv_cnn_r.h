@@ -67,6 +67,12 @@ struct CnnRArgs {
 #ifndef NRV_FEXP
 #define NRV_FEXP 0                                   // timing experiments on the FRONT form: 1 no read branch, 2 no 6 -> 16, 4 no conv units
 #endif
+#ifndef NRV_CNNR_MED3
+#define NRV_CNNR_MED3 1
+#endif
+#ifndef NRV_CNNR_MIX
+#define NRV_CNNR_MIX 1
+#endif
 #ifndef NRV_CNNR_SGB
 #define NRV_CNNR_SGB 1
 #endif
@@ -176,6 +182,19 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
 #define b1v K.b1
 #define s1v K.s1
 #define h1v K.h1
+  // ReLU of a matrix-instruction result as v_med3_f32(x, 0, 3e38): written as fmaxf, hipcc puts a canonicalising
+  // v_max_f32 x, x in front of every v_max_f32 0, x (104 extra instructions per unit).
+#if NRV_CNNR_MED3
+  auto relu_acc = [](float x) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f); };
+#else
+  auto relu_acc = [](float x) __attribute__((always_inline)) { return __builtin_fmaxf(x, 0.f); };
+#endif
+#if NRV_CNNR_MIX
+  float m1; asm("s_mov_b32 %0, 0xbf800000" : "=s"(m1));   // -1, opaque: x - (float)hi as v_fma_mix_f32 (no v_cvt_f32_f16)
+#define NRV_LO(x, h) __builtin_fmaf((float)(h), m1, (x))
+#else
+#define NRV_LO(x, h) ((x) - (float)(h))
+#endif
   // Ring slot of position pos: pos % 12.  A quarter's positions C + q never wrap for C % 12 <= 8, so the slot is an
   // immediate offset on ONE per-lane address (rq); the two bases that can wrap (C % 12 = 9, 11) have their own.
   lds_h* const rq = c1 + q * kCnnRSlot + n * 8;
@@ -210,7 +229,7 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     for (int o = 0; o < 8; o += 2) {
       const f16x2r hp = __builtin_convertvector(f32x2r{c[o], c[o + 1]}, f16x2r);
       hi[o] = hp[0]; hi[o + 1] = hp[1];
-      const f16x2r lp = __builtin_convertvector(f32x2r{c[o] - (float)hp[0], c[o + 1] - (float)hp[1]}, f16x2r);
+      const f16x2r lp = __builtin_convertvector(f32x2r{NRV_LO(c[o], hp[0]), NRV_LO(c[o + 1], hp[1])}, f16x2r);
       lo[o] = lp[0]; lo[o + 1] = lp[1];
     }
     *(lds_h8*)d = hi;
@@ -348,12 +367,12 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
         const float xs = pi ? xr1 : xr0;
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(__builtin_fmaxf(acc[r], 0.f), k1[r], k2[r] + xs);
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(relu_acc(acc[r]), k1[r], k2[r] + xs);
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           const f16x2r hp = __builtin_convertvector(f32x2r{v[r], v[r + 1]}, f16x2r);
           fb_hi[4 * pi + r] = hp[0]; fb_hi[4 * pi + r + 1] = hp[1];
-          const f16x2r lp = __builtin_convertvector(f32x2r{v[r] - (float)hp[0], v[r + 1] - (float)hp[1]}, f16x2r);
+          const f16x2r lp = __builtin_convertvector(f32x2r{NRV_LO(v[r], hp[0]), NRV_LO(v[r + 1], hp[1])}, f16x2r);
           fb_lo[4 * pi + r] = lp[0]; fb_lo[4 * pi + r + 1] = lp[1];
         }
       }
@@ -381,6 +400,7 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
   if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(args.sat, 1u);
 }
 
+#undef NRV_LO
 #undef w1v
 #undef b1v
 #undef s1v
