@@ -4,7 +4,7 @@
 mkdir -p /tmp/study
 cd /root/repo/nanoreviser_amd/csrc || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -c nrv_api.hip \
-  -Rpass-analysis=kernel-resource-usage -fno-slp-vectorize -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000 \
+  -Rpass-analysis=kernel-resource-usage -fno-slp-vectorize -mllvm -enable-post-misched=0 -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000 \
   -o /tmp/study/dev.o 2> /tmp/study/res.txt
 grep -E "error" /tmp/study/res.txt | head
 grep -A11 "Function Name: .*${1:-lstm}" /tmp/study/res.txt | grep "Name\|VGPRs:\|AGPRs\|Spill\|ScratchSize\|LDS" | sed 's/.*remark: //;s/\[-R.*//'

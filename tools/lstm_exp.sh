@@ -8,7 +8,7 @@
 #   tools/lstm_exp.sh 1 3 7 15 ...   -> exp/libnanorev_hip_exp<bits>.so     (scripts/gpu_exp.sh 1 3 7 15)
 cd "$(dirname "$0")/../nanoreviser_amd/csrc" || exit 1
 mkdir -p exp
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DNRV_EXPERIMENTS=1 -fno-slp-vectorize -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DNRV_EXPERIMENTS=1 -fno-slp-vectorize -mllvm -enable-post-misched=0 -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000"
 for v in "$@"; do
   if [ "$v" = knobs ]; then
     ( /opt/rocm/bin/hipcc $FLAGS -o exp/libnanorev_hip_experiments.so nrv_api.hip > exp/build_knobs.log 2>&1; echo "knobs rc=$?" ) &
