@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
   }
   __syncthreads();
 
+  const float m1 = neg_one_opaque();
   constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};          // (weight term, activation term): lo*hi, hi*lo, hi*hi
   auto frag = [&](int f) __attribute__((always_inline)) { return *(const f16x8*)(wl + f * 512 + lane * 8); };
   auto bias_tile = [&](int off) __attribute__((always_inline)) {       // C-layout bias of 32 features at off
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
       lo[j] = relu_nan(z[base + j] * c);
       hi[j] = relu_nan(z[base + 4 + j] * c);
     }
-    return split2(lo, hi);
+    return split2(lo, hi, m1);
   };
   const unsigned av = l31 * 16 + half * 512;                   // chunk 4*kb + 2*term + half, row l31
   auto load_x = [&](int u, f32x4 (&x)[8][2]) __attribute__((always_inline)) {

@@ -62,6 +62,31 @@ __device__ __forceinline__ Split2 split2(const f32x4& lo4, const f32x4& hi4) {
   return o;
 }
 
+// The same split with the low terms as v_fma_mix_f32(hi, -1, x): four instructions per pair instead of six.  (With the
+// low terms converted by the same instruction, v_fma_mixlo / mixhi_f16 - three per pair - the signal branch and the
+// 32->64 layer were measured SLOWER, r03.)  m1 is
+// -1.0f in a register the compiler cannot see through (neg_one_opaque(), once per kernel): written as x - (float)h
+// the subtraction needs v_cvt_f32_f16 first.
+__device__ __forceinline__ float neg_one_opaque() {
+  float m1;
+  asm("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
+  return m1;
+}
+__device__ __forceinline__ Split2 split2(const f32x4& lo4, const f32x4& hi4, const float m1) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  Split2 o;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const float x0 = j < 4 ? lo4[j] : hi4[j - 4], x1 = j < 4 ? lo4[j + 1] : hi4[j - 3];
+    const h2_t h = __builtin_convertvector(f2_t{x0, x1}, h2_t);
+    const h2_t l = __builtin_convertvector(f2_t{__builtin_fmaf((float)h[0], m1, x0), __builtin_fmaf((float)h[1], m1, x1)}, h2_t);
+    o.t[0][j] = h[0]; o.t[0][j + 1] = h[1];
+    o.t[1][j] = l[0]; o.t[1][j + 1] = l[1];
+  }
+  return o;
+}
+
 __device__ __forceinline__ f32x16 mfma_f16(const f16x8& a, const f16x8& b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
