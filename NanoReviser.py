@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """NanoReviser.py - same command line as the reference's script of this name, served by the
 MI355X engine (see nanoreviser_amd/cli.py for what is kept and what is changed)."""
+import os
 import sys
 
-from nanoreviser_amd.cli import main
+# One BLAS thread per process: this command line and its parser workers never call BLAS, and on a 256-CPU host
+# every `import numpy` otherwise starts an OpenBLAS pool sized for the machine - in each of the --thread workers at once.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+from nanoreviser_amd.cli import main  # noqa: E402
 
 if __name__ == "__main__":
     sys.exit(main(standalone=True))

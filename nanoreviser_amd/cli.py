@@ -322,6 +322,20 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     on_file(fn, revised): called once per file when its output is final (revised, or the original
     basecalls after a failure; revised=False also for files that could not be parsed at all)."""
     stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
+    # NRV_CLI_TRACE=1: where the wall time of this call goes (first device call, engine idle gaps, tail), to the log
+    trace, t_start = ([] if os.environ.get("NRV_CLI_TRACE") else None), time.perf_counter()
+    if trace is not None:
+        try:                                          # age of this process: interpreter start, imports, main() so far
+            with open("/proc/self/stat") as f:
+                ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+            with open("/proc/uptime") as f:
+                trace.append(("mark", 0.0, f"process age {float(f.read().split()[0]) - ticks / os.sysconf('SC_CLK_TCK'):.2f} s at"))
+        except Exception:
+            pass
+
+    def mark(what):
+        if trace is not None:
+            trace.append(("mark", time.perf_counter() - t_start, what))
     note = on_file or (lambda fn, ok: None)
     # `reviser` may be a zero-argument factory: the engine is then created by the engine thread as its first task,
     # i.e. WHILE the parser pool starts and the first reads are parsed (nrv_create: HIP context + weight packing,
@@ -334,12 +348,19 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
 
     # Files per worker task: one task = one device call (>= kBatchEvents events at ~6.5 k events per read); the
     # worker hands back the reads of a task already concatenated (`_load_bundle`).
-    kBatchEvents = 8 * max(int(getattr(args, "batch", 4096)), 1024)
-    per_task = max(1, min(16, kBatchEvents // 6500))
+    # 16 launch groups per device call (r03, 4000 reads: 8 -> 7.6, 16 -> 10.2, 32 -> 10.3 M bases/s end to end: a call's
+    # pipeline fill / drain is paid once per call), but never so many reads per task that the workers run dry
+    kBatchEvents = int(os.environ.get("NRV_CLI_GROUPS", "16")) * max(int(getattr(args, "batch", 4096)), 1024)
+    per_task = max(1, min(32, kBatchEvents // 6500, -(-len(jobs) // (2 * nworkers))))
 
     pool = None
     if nworkers > 1 and len(files) >= 4:
         import multiprocessing as mp
+        # The workers never call BLAS; without a cap every one of them starts, at `import numpy`, an OpenBLAS pool sized
+        # for the machine (256 CPUs on the GPU boxes, 16 in the cgroup): the first parsed reads came back after 0.73 s
+        # instead of 0.15 s (r03, scripts/gpu_cli_trace.sh).  Inherited through the environment of the spawned children.
+        for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            os.environ.setdefault(v, "1")
         pool = ProcessPoolExecutor(nworkers, mp_context=mp.get_context("spawn"))
 
     def results():
@@ -352,8 +373,14 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         pend = deque()
         for k in range(0, len(jobs), per_task):
             pend.append(pool.submit(_load_bundle, jobs[k:k + per_task]))
+            if k == 0:
+                mark("first task submitted (workers started)")
             if len(pend) >= 3 * nworkers:
+                if len(pend) == 3 * nworkers and k == (3 * nworkers - 1) * per_task:
+                    mark("3 x workers tasks submitted")
                 yield pend.popleft().result()
+                if k == (3 * nworkers - 1) * per_task:
+                    mark("first bundle back")
         while pend:
             yield pend.popleft().result()
 
@@ -422,6 +449,10 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         """Engine thread: one device call for the batch; merging and writing go to the finisher."""
         reviser = box["rv"]
         t0 = time.perf_counter()
+        ti = None
+        if trace is not None:
+            ti = len(trace)
+            trace.append(("call", t0 - t_start, 0.0))
         rts = _bundle_reads(bundle) if bundle is not None else [rt for _, rt, _ in batch]
         try:
             if bundle is not None and packed is not None:
@@ -441,6 +472,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                 except Exception as e:
                     calls.append(e)
         stats["engine_s"] += time.perf_counter() - t0
+        if ti is not None:
+            trace[ti] = ("call", t0 - t_start, time.perf_counter() - t0)
         return fin.submit(finish_batch, batch, calls)
 
     # reads are grouped into device calls of >= kBatchEvents events; the engine runs in its own
@@ -454,7 +487,7 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             stack.callback(lambda: pool.shutdown(wait=False, cancel_futures=True))
         eng = stack.enter_context(ThreadPoolExecutor(1))
         fin = stack.enter_context(ThreadPoolExecutor(1))
-        created = eng.submit(lambda: box.__setitem__("rv", reviser())) if lazy else None
+        created = eng.submit(lambda: (box.__setitem__("rv", reviser()), mark("engine created"))) if lazy else None
 
         def submit(batch, bundle=None):
             # the NumPy half of the device call (descriptors, output arrays; for unbundled reads also the concatenation)
@@ -509,6 +542,16 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         if created is not None:
             created.result()
         collect_finished(True)
+    if trace:
+        t_end = time.perf_counter() - t_start
+        calls = [c for c in trace if c[0] == "call"]
+        busy = sum(c[2] for c in calls)
+        gaps = sorted((calls[i + 1][1] - (calls[i][1] + calls[i][2]) for i in range(len(calls) - 1)), reverse=True)
+        log("[trace] " + "; ".join(f"{w} {t:.3f} s" for k, t, w in trace if k == "mark"))
+        log(f"[trace] process_files {t_end:.3f} s: first device call at {calls[0][1]:.3f} s, {len(calls)} calls busy {busy:.3f} s, "
+            f"idle between calls {sum(gaps):.3f} s (largest {[round(g, 4) for g in gaps[:5]]}), "
+            f"tail after the last call {t_end - calls[-1][1] - calls[-1][2]:.3f} s; first call {calls[0][2]:.3f} s, "
+            f"median call {sorted(c[2] for c in calls)[len(calls) // 2]:.4f} s")
     reviser = box["rv"]
     sat = getattr(reviser, "saturated", None)
     if callable(sat):                                 # f16x2 range guard: stages re-run on the f32 kernels

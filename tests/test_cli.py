@@ -157,6 +157,7 @@ def test_dead_worker_bookkeeping_uses_reported_files_not_file_existence(tmp_path
     for n in names:
         shutil.copy(src[0] if n.endswith("A") else src[1], d / (n + ".fast5"))
     monkeypatch.setattr(cli, "shard_reads", lambda sizes, world: [[0, 1, 2, 3], [4, 5, 6, 7]])
+    monkeypatch.setenv("NRV_CLI_GROUPS", "8")         # device calls of two of these reads (8 x 1024 events), as the scenario needs
     out = str(tmp_path) + "/o/"
     os.makedirs(out)
     open(out + "r6_B_out.fasta", "w").write("STALE OUTPUT OF AN EARLIER RUN")
