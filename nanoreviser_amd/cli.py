@@ -342,6 +342,19 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     # 0.15-0.3 s that used to precede everything else)
     lazy = callable(reviser) and not hasattr(reviser, "predict_read")
     box = {"rv": None if lazy else reviser}
+    # NRV_CLI_ENGINES=n: n engines on the same device, each driven by its own thread, so that the pipeline fill / drain
+    # of one engine's device call overlaps the other's kernels.  Measured (r03, 4000 reads, 16 launch groups per call):
+    # 1 engine 11.0, 2 engines 10.1-10.4, 3 engines 10.0 M bases/s end to end - the device is already the limit and the
+    # two engines' persistent kernels get in each other's way - so the default stays ONE; the knob is kept, tested.
+    import queue
+    import threading
+    n_eng = max(1, int(os.environ.get("NRV_CLI_ENGINES", "1"))) if lazy else 1
+    free = queue.Queue()                              # engines not inside a call
+    engines = []
+    if not lazy:
+        free.put(reviser)
+        engines.append(reviser)
+    stats_lock = threading.Lock()
     nworkers = max(1, min(int(args.thread), os.cpu_count() or 1, 32, max(1, len(files))))
     jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup)
             for fn in files]
@@ -447,7 +460,13 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
 
     def run_batch(batch, packed=None, bundle=None):
         """Engine thread: one device call for the batch; merging and writing go to the finisher."""
-        reviser = box["rv"]
+        reviser = free.get()                          # an engine that is not inside a call (all have the same T, weights)
+        try:
+            return run_batch_on(reviser, batch, packed, bundle)
+        finally:
+            free.put(reviser)
+
+    def run_batch_on(reviser, batch, packed, bundle):
         t0 = time.perf_counter()
         ti = None
         if trace is not None:
@@ -471,7 +490,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                     calls.append(predict_one(reviser, rt))
                 except Exception as e:
                     calls.append(e)
-        stats["engine_s"] += time.perf_counter() - t0
+        with stats_lock:
+            stats["engine_s"] += time.perf_counter() - t0
         if ti is not None:
             trace[ti] = ("call", t0 - t_start, time.perf_counter() - t0)
         return fin.submit(finish_batch, batch, calls)
@@ -485,9 +505,32 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     with contextlib.ExitStack() as stack:
         if pool is not None:                          # whatever happens below, the parser pool does not outlive us
             stack.callback(lambda: pool.shutdown(wait=False, cancel_futures=True))
-        eng = stack.enter_context(ThreadPoolExecutor(1))
+        eng = stack.enter_context(ThreadPoolExecutor(n_eng))
         fin = stack.enter_context(ThreadPoolExecutor(1))
-        created = eng.submit(lambda: (box.__setitem__("rv", reviser()), mark("engine created"))) if lazy else None
+
+        def create(first):
+            try:
+                rv = reviser()
+            except BaseException as e:
+                if first:
+                    raise                             # no engine at all: loud (submit() re-raises it)
+                log(f"[s:::] a second engine on this device could not be created ({e!r}): continuing with one")
+                return
+            if first:
+                box["rv"] = rv
+            engines.append(rv)
+            free.put(rv)
+            mark("engine created")
+
+        def create_next():
+            try:
+                created.result()                      # one at a time, the first one first
+            except BaseException:
+                return
+            create(False)
+        created = eng.submit(create, True) if lazy else None
+        for _ in range(n_eng - 1):
+            eng.submit(create_next)
 
         def submit(batch, bundle=None):
             # the NumPy half of the device call (descriptors, output arrays; for unbundled reads also the concatenation)
@@ -531,10 +574,10 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                 if nev >= kBatchEvents:
                     inflight.append(submit(batch))
                     batch, nev = [], 0
-                    drain(2)
+                    drain(n_eng + 1)
             if bundled:
                 inflight.append(submit(bundled, bundle))
-                drain(2)
+                drain(n_eng + 1)
             collect_finished(False)
         if batch:
             inflight.append(submit(batch))
@@ -545,17 +588,18 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     if trace:
         t_end = time.perf_counter() - t_start
         calls = [c for c in trace if c[0] == "call"]
-        busy = sum(c[2] for c in calls)
-        gaps = sorted((calls[i + 1][1] - (calls[i][1] + calls[i][2]) for i in range(len(calls) - 1)), reverse=True)
+        calls.sort(key=lambda c: c[1])
+        busy, idle, end = sum(c[2] for c in calls), 0.0, calls[0][1]
+        for _, t, d in calls:                         # time with NO engine inside a call, between the first and the last call
+            idle += max(0.0, t - end)
+            end = max(end, t + d)
         log("[trace] " + "; ".join(f"{w} {t:.3f} s" for k, t, w in trace if k == "mark"))
-        log(f"[trace] process_files {t_end:.3f} s: first device call at {calls[0][1]:.3f} s, {len(calls)} calls busy {busy:.3f} s, "
-            f"idle between calls {sum(gaps):.3f} s (largest {[round(g, 4) for g in gaps[:5]]}), "
-            f"tail after the last call {t_end - calls[-1][1] - calls[-1][2]:.3f} s; first call {calls[0][2]:.3f} s, "
+        log(f"[trace] process_files {t_end:.3f} s: first device call at {calls[0][1]:.3f} s, {len(calls)} calls on "
+            f"{len(engines)} engine(s), {busy:.3f} s summed, no call running for {idle:.3f} s, "
+            f"tail after the last call {t_end - end:.3f} s; first call {calls[0][2]:.3f} s, "
             f"median call {sorted(c[2] for c in calls)[len(calls) // 2]:.4f} s")
-    reviser = box["rv"]
-    sat = getattr(reviser, "saturated", None)
-    if callable(sat):                                 # f16x2 range guard: stages re-run on the f32 kernels
-        stats["range_reruns"] = int(sat()[1])
+    if any(callable(getattr(rv, "saturated", None)) for rv in engines):   # f16x2 range guard: stages re-run on the f32 kernels
+        stats["range_reruns"] = sum(int(rv.saturated()[1]) for rv in engines if callable(getattr(rv, "saturated", None)))
         if stats["range_reruns"]:
             log(f"[s:::] {stats['range_reruns']} device stage(s) held out-of-range signal (spikes / tiny MAD) "
                 "and were computed on the f32 kernels")
@@ -686,7 +730,7 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
 
             def make():                               # runs in the engine thread, beside the parser pool's start-up
                 made.append((worker_factory or _default_factory)(args, 0))
-                return made[0]
+                return made[-1]                       # called once per engine (process_files: NRV_CLI_ENGINES)
             stats = [process_files(args, names, make, print)]
             for rv in made:
                 rv.close()

@@ -89,3 +89,30 @@ def shared_device_factory(args, device):
     """The REAL engine for every worker rank, all on device 0 (a 1-GPU box rehearsing the N-worker path)."""
     from nanoreviser_amd import cli
     return cli._default_factory(args, 0)
+
+
+class _ExclusiveEcho(EchoEngine):
+    """An engine is one native handle: never inside two calls at once.  Counts the engines made and the violations."""
+    made = []
+    violations = []
+
+    def __init__(self):
+        super().__init__()
+        import threading
+        self._in_call = threading.Lock()
+        _ExclusiveEcho.made.append(self)
+
+    def predict_read(self, sig_ev, feat_ev):
+        import time
+        if not self._in_call.acquire(blocking=False):
+            _ExclusiveEcho.violations.append(id(self))
+            raise RuntimeError("engine entered by two threads at once")
+        try:
+            time.sleep(0.02)                               # long enough for the calls of two engine threads to overlap
+            return super().predict_read(sig_ev, feat_ev)
+        finally:
+            self._in_call.release()
+
+
+def exclusive_factory(args, device):
+    return _ExclusiveEcho()

@@ -10,7 +10,7 @@ import pytest
 from conftest import GOLD, load_read
 from nanoreviser_amd import cli
 from nanoreviser_amd import hoststage as hs
-from echo_engine import (EchoEngine, echo_factory, dying_factory, dying_midway_factory, broken_factory,
+from echo_engine import (EchoEngine, _ExclusiveEcho, exclusive_factory, echo_factory, dying_factory, dying_midway_factory, broken_factory,
                          fails_then_dies_factory)
 
 FAST5 = os.path.join(GOLD, "fast5")
@@ -204,6 +204,34 @@ def test_pooled_workers_hand_over_bundles(tmp_path, fail):
     else:
         assert failed == []
     assert eng.calls >= 2                                              # at least two bundles (+ retries)
+
+
+def test_two_engines_per_device_are_two_engines(tmp_path, monkeypatch):
+    """NRV_CLI_ENGINES=2: the engine factory is called twice, the two engine threads
+    never share an engine (r03: the factory wrapper handed the FIRST engine out twice - two threads inside one native
+    handle - and whole launch groups came back wrong), and the files are those of a one-engine run."""
+    import shutil
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    names = [f"e{i}_{'AB'[i % 2]}" for i in range(12)]
+    for n in names:
+        shutil.copy(src[0] if n.endswith("A") else src[1], d / (n + ".fast5"))
+    out = str(tmp_path) + "/o/"
+    _ExclusiveEcho.made.clear()
+    _ExclusiveEcho.violations.clear()
+    monkeypatch.setenv("NRV_CLI_ENGINES", "2")
+    monkeypatch.setenv("NRV_CLI_GROUPS", "2")          # several device calls for these twelve reads
+    rc = cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "2", "--batch", "1024", "-e", "bad.txt"],
+                  worker_factory=exclusive_factory, world=1)
+    assert rc == 0
+    assert len(_ExclusiveEcho.made) == 2 and _ExclusiveEcho.made[0] is not _ExclusiveEcho.made[1]
+    assert _ExclusiveEcho.violations == []
+    assert all(e.calls >= 1 for e in _ExclusiveEcho.made)               # both engines served calls
+    assert open(out + "bad.txt").read().split() == []
+    orig = {"A": _orig(os.path.basename(src[0])), "B": _orig(os.path.basename(src[1]))}
+    for n in names:
+        assert open(out + n + "_out.fasta").read() == ">" + n + ".fast5\n" + orig[n[-1]]
 
 
 def test_vlen_string_fastq_does_not_discard_the_read(monkeypatch):
