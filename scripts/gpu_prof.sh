@@ -14,4 +14,4 @@ find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_all_dispat
 PMC_OUT=$O/pmc_$PREC BENCH_EXTRA="--precision $PREC" bash scripts/gpu_pmc.sh > $O/pmc_$PREC.log 2>&1
 python3 tools/parse_pmc.py $O/pmc_$PREC $O/pmc_summary_$PREC.json > /dev/null 2>&1
 rm -rf $O/prof_kt $O/pmc_$PREC/pass*/
-tail -1 $O/prof_kt_$PREC.log | cut -c1-900; cat $O/kernel_stats_timed_region_$PREC.txt
+grep "^{\"metric" $O/prof_kt_$PREC.log | tail -1 | cut -c1-900; cat $O/kernel_stats_timed_region_$PREC.txt
