@@ -11,8 +11,10 @@
  *
  * Conventions: plain pointers and sizes only.  Every function returns 0 on success and a
  * negative nrv_status otherwise; nothing throws.  The engine copies weights at create time and
- * never keeps a caller pointer past the return of a call.  One handle per (process, GPU); calls
- * on one handle are not re-entrant.  There is NO CPU fallback: without a usable HIP device
+ * never keeps a caller pointer past the return of a call.  Calls on ONE handle are not
+ * re-entrant (one caller at a time: two threads inside the same handle corrupt whole launch
+ * groups); SEVERAL handles per (process, GPU) may be driven by several threads at once
+ * (scripts/gpu_two_engines.py; the device is shared, so this buys overlap, not throughput).  There is NO CPU fallback: without a usable HIP device
  * nrv_create fails with NRV_E_NO_DEVICE.
  */
 #ifndef NANOREV_H
