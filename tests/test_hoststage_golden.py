@@ -190,3 +190,25 @@ def test_f32_window_fast_path_equals_cast_of_reference_matrix(reads):
     w64, _, _, shift, scale = hs.signal_segmentation(raw, st, 3)
     assert np.array_equal(hs.segment_windows_f32(raw, st, shift, scale), w64.astype(np.float32))
     assert np.array_equal(hs.segment_windows_f32(raw.astype(np.float64), st, shift, scale), w64.astype(np.float32))
+
+
+def test_median_mad_of_integer_samples_is_numpy_median_exactly():
+    """hoststage.median_mad takes shift / scale of int16 samples from a histogram; they must be the SAME f64 numbers
+    np.median gives on the f64 copy (preprocessing.py:100-101), for odd and even counts, half-integer shifts, the
+    extremes of the type - and anything that is not a small integer type goes through np.median itself."""
+    rng = np.random.default_rng(7)
+    for trial in range(400):
+        n = int(rng.integers(1, 60)) if trial % 2 else int(rng.integers(1000, 20000))
+        lo = int(rng.integers(-32768, 32700))
+        hi = int(rng.integers(lo + 1, min(lo + 1 + int(rng.integers(1, 2000)), 32768)))
+        raw = rng.integers(lo, hi, n).astype(np.int16)
+        r64 = raw.astype(np.float64)
+        shift = np.median(r64)
+        scale = np.median(np.abs(r64 - shift))
+        got = hs.median_mad(raw)
+        assert got[0] == shift and got[1] == scale and isinstance(got[0], np.float64), (n, lo, hi)
+    for raw in (np.array([-32768, 32767], np.int16), np.array([5], np.int16), np.arange(256, dtype=np.uint8)):
+        r64 = raw.astype(np.float64)
+        assert hs.median_mad(raw) == (np.median(r64), np.median(np.abs(r64 - np.median(r64))))
+    x = rng.normal(size=101)                      # not integer samples: the plain path
+    assert hs.median_mad(x) == (np.median(x), np.median(np.abs(x - np.median(x))))
