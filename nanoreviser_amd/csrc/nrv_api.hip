@@ -859,17 +859,29 @@ static int lanes_wanted(const nrv_handle* h) {
   return w > nrv_handle::kMaxLanes ? nrv_handle::kMaxLanes : w;
 }
 // Windows per pipeline stage of the host-pointer entry points (one upload, its groups, one download).
-static int stage_windows(const nrv_handle* h) {
+// READ modes (one event per window crosses PCIe, 92-270 B per base) take several full-size groups per stage
+// (NRV_READ_STAGE, default kReadStageGroups): fewer uploads, events and hand-overs per call - r03, same box:
+// nrv_predict_reads_raw 11.9 / 12.4 / 12.5 M bases/s with 1 / 2 / 4 groups per stage, nrv_predict_read 11.6 / 11.7 /
+// 12.0.  The same stage in WINDOW mode (2958 B per base) halves nrv_predict (9.3 -> 4.7 M with 2): its pipeline
+// then has too few stages to hide PCIe behind the kernels, so window mode keeps one group per stage.
+constexpr int kReadStageGroups = 4;
+static int read_stage_groups(const nrv_handle* h) {
+  static const int env = getenv("NRV_READ_STAGE") ? atoi(getenv("NRV_READ_STAGE")) : kReadStageGroups;
+  return (lanes_wanted(h) > 1 || env < 1) ? 1 : (env > 8 ? 8 : env);
+}
+static int stage_windows(const nrv_handle* h, bool read_mode = false) {
   const int w = lanes_wanted(h);
-  return w > 1 ? w * h->batch : h->batch;
+  if (w > 1) return w * h->batch;
+  return read_mode ? read_stage_groups(h) * h->batch : h->batch;
 }
 
 static int ensure_workspace(nrv_handle* h) {
   const int T = h->T;
-  int rows = ((stage_windows(h) + kRowPad - 1) / kRowPad) * kRowPad;
+  const int rows = ((stage_windows(h, true) + kRowPad - 1) / kRowPad) * kRowPad;   // staging: the larger (read-mode) stage
   if (rows <= h->cap_rows) return NRV_OK;
   free_workspace(h);
-  const size_t tiles = rows / 32;
+  // activations: ONE launch group (a stage's groups run one after the other on these, or on the lanes' own sets)
+  const size_t tiles = (size_t)(((h->batch + kRowPad - 1) / kRowPad) * kRowPad) / 32;
   // event-major S needs (rows + T + 32) events; window-major S needs rows*T "events"
   for (int m = 0; m < 2; ++m) {
     size_t nS = (tiles * T + 2) * 16 * 128, n1 = tiles * T * 8 * 128, n2 = tiles * T * 32 * 128,
@@ -1707,7 +1719,7 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   const bool direct_s = !raw_reads && pin_s.pin(h, sig, ev_all * kSig * 4);
   const bool direct_f = pin_f.pin(h, feat, ev_all * kFeat * 4);
   // a pipeline stage = one upload, its launch groups (on the lanes when groups are small), one download
-  const int stage = stage_windows(h);
+  const int stage = stage_windows(h, read_mode);
   const size_t ev_grp = read_mode ? (size_t)(stage + T - 1) : (size_t)stage * T;
   if (!raw_reads && !direct_s && (rc = grow_pinned(h, h->pin_sig, &h->pin_sig_cap, ev_grp * kSig * 4))) return rc;
   if (!direct_f && (rc = grow_pinned(h, h->pin_feat, &h->pin_feat_cap, ev_grp * kFeat * 4))) return rc;
