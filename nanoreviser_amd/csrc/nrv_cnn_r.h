@@ -236,8 +236,12 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     *(lds_h8*)(d + 16 * 8) = lo;
   };
 
-  // units of 16 events: unit u = 2 * tile + sub, dealt round-robin over all waves of the launch's workgroups
-  for (int u = blockIdx.x * kCnnRWaves + wave; u < n_units; u += gridDim.x * kCnnRWaves) {
+  // units of 16 events: unit u = 2 * tile + sub
+  // Units are dealt WORKGROUP-first (unit u -> workgroup u % G, then that workgroup's waves in turn): the bench step's
+  // 3328 units per model over 128 workgroups are exactly 26 each, 6 or 7 per SIMD.  Dealt wave-first (u -> wave
+  // u % 1024 of the launch, r03e-r03k) the first 32 workgroups had 8 per SIMD and the others 6, and the launch waited
+  // for those 32: 53.3 -> 47.1 us on the same box.
+  for (int u = blockIdx.x + gridDim.x * wave; u < n_units; u += gridDim.x * kCnnRWaves) {
     const int b = u >> 1, sub = u & 1;
     const int wt = b / T, t = b % T;
     const int row = 16 * sub + n;
