@@ -37,6 +37,20 @@ def test_header_symbols_exported(lib):
     assert sorted(engine.SYMBOLS) == names
 
 
+def test_host_helper_header_symbols_exported():
+    """include/nanorev_host.h <-> libnanorev_host.so (plain C, gcc): every declared nrvh_* symbol is exported."""
+    import __graft_entry__ as g
+    from nanoreviser_amd import hostlib
+    g.build_host()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nanorev_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(nrvh_[a-z_0-9]+)\s*\(", txt)))
+    assert names == sorted(hostlib.SYMBOLS) and len(names) >= 2
+    lib = C.CDLL(hostlib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nanorev_host.h but not exported"
+    assert "libamdhip64" not in os.popen(f"readelf -d {hostlib.LIB_PATH}").read()      # host only
+
+
 def test_no_oracle_or_cpu_path_in_product():
     """The product package must not import or link anything under oracle/."""
     pkg = os.path.join(ROOT, "nanoreviser_amd")

@@ -212,3 +212,66 @@ def test_median_mad_of_integer_samples_is_numpy_median_exactly():
         assert hs.median_mad(raw) == (np.median(r64), np.median(np.abs(r64 - np.median(r64))))
     x = rng.normal(size=101)                      # not integer samples: the plain path
     assert hs.median_mad(x) == (np.median(x), np.median(np.abs(x - np.median(x))))
+
+
+def _per_event_numpy(raw, st, last):
+    r64 = np.asarray(raw).astype(np.float64)
+    n = len(st)
+    m, s = np.empty(n), np.empty(n)
+    for i in range(n):
+        seg = r64[st[i]:(st[i + 1] if i + 1 < n else st[i] + last)]
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m[i], s[i] = (seg.mean(), seg.std()) if len(seg) else (np.nan, np.nan)
+    return m, s
+
+
+def test_native_event_stats_is_numpy_bit_for_bit():
+    """libnanorev_host.so (include/nanorev_host.h): per-event mean / std with NumPy's own summation order - every
+    branch of it (fewer than 8 values, the eight running sums up to 128, the halving above) - equals np.mean / np.std
+    of the slice exactly, as do the grouped NumPy formulation it replaces and the clipped / empty ranges."""
+    from nanoreviser_amd import hostlib
+    import __graft_entry__ as g
+    g.build_host()
+    hostlib._tried = False
+    assert hostlib.load() is not None, "libnanorev_host.so must build with gcc"
+    rng = np.random.default_rng(11)
+    n_events = 0
+    for trial in range(60):
+        nev = int(rng.integers(1, 120))
+        lens = rng.integers(1, [12, 40, 140, 300, 1200][trial % 5], nev)
+        st = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        L = max(int(lens.sum()) - int(rng.integers(0, 3)) * (trial % 2), 1)      # sometimes the last event is clipped
+        lo = int(rng.integers(-32768, 32000))
+        raw = rng.integers(lo, min(lo + 1 + int(rng.integers(1, 4000)), 32768), L).astype(np.int16)
+        got = hostlib.event_stats(raw, st, int(lens[-1]))
+        ref = _per_event_numpy(raw, st, int(lens[-1]))
+        assert np.array_equal(got[0], ref[0], equal_nan=True) and np.array_equal(got[1], ref[1], equal_nan=True)
+        en = np.append(st[1:], st[-1] + int(lens[-1]))
+        old = hs._event_mean_std(raw.astype(np.float64), st, en)
+        assert np.array_equal(got[0], old[0], equal_nan=True) and np.array_equal(got[1], old[1], equal_nan=True)
+        n_events += nev
+    assert n_events > 2000
+    # an event wholly past the samples: NaN, like the empty slice
+    m, s = hostlib.event_stats(np.array([1, 2, 3], np.int16), np.array([0, 2, 5]), 4)
+    assert m[0] == 1.5 and m[1] == 3.0 and np.isnan(m[2]) and np.isnan(s[2])
+    # what the helper does not take goes back to NumPy: float samples, starts beyond int32
+    assert hostlib.event_stats(np.array([1.0, 2.0]), np.array([0]), 2) is None
+    assert hostlib.event_stats(np.array([1, 2], np.int16), np.array([0, 2 ** 31]), 2) is None
+
+
+def test_event_stats_same_with_and_without_the_native_helper(monkeypatch):
+    from nanoreviser_amd import hostlib
+    rng = np.random.default_rng(12)
+    lens = rng.integers(3, 60, 500)
+    st = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    raw = rng.integers(300, 900, int(lens.sum())).astype(np.int16)
+    hostlib._tried = False
+    a = hs.event_stats(raw, st, int(lens[-1]))
+    monkeypatch.setenv("NRV_HOST_LIB", "0")
+    hostlib._tried, hostlib._lib = False, None
+    b = hs.event_stats(raw, st, int(lens[-1]))
+    hostlib._tried = False
+    assert all(np.array_equal(x, y) for x, y in zip(a[:2], b[:2])) and a[2:] == b[2:]
