@@ -15,6 +15,8 @@ if __name__ == "__main__":
     rc = main(standalone=True)
     # Every output file is final (written, renamed) and the engine is closed when main() returns; what an orderly
     # interpreter exit would add is the HIP runtime's teardown (~0.1 s of a 0.5 s two-read run), so leave directly.
+    import gc
+    gc.collect()                          # the parser pool's queues: their semaphores are unlinked by their finalizers
     sys.stdout.flush()
     sys.stderr.flush()
     os._exit(rc)

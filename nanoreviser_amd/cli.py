@@ -602,6 +602,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         if created is not None:
             created.result()
         collect_finished(True)
+        if pool is not None:                          # all work is in: an orderly end of the workers (their queues' semaphores
+            pool.shutdown(wait=True)                  # are released here, not left to the resource tracker)
     if trace:
         t_end = time.perf_counter() - t_start
         calls = [c for c in trace if c[0] == "call"]

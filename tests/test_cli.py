@@ -270,3 +270,32 @@ def test_cli_end_to_end_on_gpu(tmp_path, species_models):
         assert want[:5] == orig[:5] and set(want) <= set("ACGT")
     assert open(out + "failed_reads.txt").read() == ""
     rv.close()
+
+
+@pytest.mark.gpu
+def test_script_with_parser_pool_is_quiet_and_complete(tmp_path):
+    """`python NanoReviser.py` as a child process with a parser pool (>= 4 files, --thread 4): exit code 0, nothing on
+    stderr (the script leaves with os._exit once main() has returned - the pool must have been shut down in order, or
+    the resource tracker reports leaked semaphores), one output per read, identical to the in-process run's."""
+    import shutil
+    import subprocess
+    import sys
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    names = [f"q{i}_{'AB'[i % 2]}" for i in range(8)]
+    for n in names:
+        shutil.copy(src[i := 0 if n.endswith("A") else 1], d / (n + ".fast5"))
+    out = str(tmp_path) + "/o/"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "NanoReviser.py"), "-d", str(d), "-o", out, "-S", "ecoli",
+                        "--thread", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.strip() == "", r.stderr
+    ref = str(tmp_path) + "/ref/"
+    assert cli.main(["-d", FAST5, "-o", ref, "-S", "ecoli", "--gpus", "1"]) == 0
+    by_kind = {os.path.basename(src[0]).split(".")[0]: "A", os.path.basename(src[1]).split(".")[0]: "B"}
+    seq = {k: open(ref + stem + "_out.fasta").read().split("\n", 1)[1] for stem, k in by_kind.items()}
+    for n in names:
+        assert open(out + n + "_out.fasta").read() == ">" + n + ".fast5\n" + seq[n[-1]]
+    assert open(out + "failed_reads.txt").read() == ""
