@@ -285,7 +285,7 @@ def test_script_with_parser_pool_is_quiet_and_complete(tmp_path):
     d.mkdir()
     names = [f"q{i}_{'AB'[i % 2]}" for i in range(8)]
     for n in names:
-        shutil.copy(src[i := 0 if n.endswith("A") else 1], d / (n + ".fast5"))
+        shutil.copy(src[0] if n.endswith("A") else src[1], d / (n + ".fast5"))
     out = str(tmp_path) + "/o/"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "NanoReviser.py"), "-d", str(d), "-o", out, "-S", "ecoli",
