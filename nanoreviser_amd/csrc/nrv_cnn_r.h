@@ -30,9 +30,12 @@ namespace nrv {
 //           the only big thing in LDS, read once per unit by every wave (8 x 16-byte reads per k-step of 18 MFMAs).
 //   out     lane (n, q) holds output features 16 mt + 4 q .. + 3 of event n: 8 contiguous bytes per term of the
 //           split-plane row (instead of 16 two-byte stores), behind the range guard (nrv_cnn_f16x2.h).
-// Each conv1 position is computed by two quarters (the price of keeping everything in registers: 2 x 40 VALU per
-// pair); per 16-event unit a wave issues ~2300 vector instructions, 231 MFMAs, 104 + ~100 LDS reads.
-// A wave owns whole units, eight such waves per workgroup (two per SIMD), persistent: one workgroup per CU and model.
+// conv1 runs once per position: a wave-private LDS ring carries its result from the quarter that computed it to the
+// three quarters that need it as their tap (2 stores + 4 reads per k-step).  The 13 k-steps are unrolled, so ring
+// slots and sample addresses are immediate offsets; per 16-event unit a wave issues ~1360 vector instructions,
+// 246 MFMAs, 104 + 52 LDS reads, 26 LDS writes, ~40 loads.
+// A wave owns whole units (dealt workgroup-first: the bench step's 3328 units per model are 26 per workgroup), eight
+// such waves per workgroup (two per SIMD), persistent: one workgroup per CU and model.
 //
 // FOUR MORE WAVES per workgroup run the first read-branch layer, Bi-LSTM(6 -> 16) (lstm1_unit, nrv_lstm1.h: one wave
 // = 16 rows of one direction, f32 16x16x4 tiles, weights in registers, wave-private).  That layer is independent of
