@@ -1167,7 +1167,11 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         h2_fused_l1 = h2_fused_l2 = true;
       }
 #endif
-      const int wg = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves;
+      // workgroups per model: enough for the conv units (8 waves each) AND for the 6 -> 16 layer's units (4 waves each,
+      // 2 units per 16 windows) - in read mode the signal branch runs per EVENT (n + T - 1 of them) but the 6 -> 16 layer
+      // still per (window, step): sized by the conv units alone its 512 units queued on 33 workgroups
+      const int wg_c = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves, wg_l = (2 * ((n + 15) / 16) + kCnnRL1Waves - 1) / kCnnRL1Waves;
+      const int wg = wg_c > wg_l ? wg_c : wg_l;
       if (h2_fused_l2) {}
       else if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
       else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
