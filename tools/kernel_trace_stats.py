@@ -4,8 +4,9 @@
 `rocprofv3 --kernel-trace --stats` averages every dispatch of the process, including the ~300 priming steps
 whose first launches run on a cold clock (round 2: 165.0 us for lstm3 in the summary against 155.6 us from the
 hipEvent pairs inside the timed region).  bench.py's dispatch sequence is fixed - 1 parity-guard step, P priming
-steps, W warm-up steps, K timed steps, then an untimed all-kernel pass - so the timed region is the dispatches
-[1 + P + W, 1 + P + W + K) of every kernel.  This tool keeps exactly those and writes a CSV in the layout of
+steps, S settling steps (blocks of 200 until the step time is stable; the count is in the run's JSON line), W warm-up
+steps, K timed steps, then an untimed all-kernel pass - so the timed region is the dispatches
+[1 + P + S + W, 1 + P + S + W + K) of every kernel.  This tool keeps exactly those and writes a CSV in the layout of
 rocprofv3's *_kernel_stats.csv, so that its average must agree with the JSON line's roofline.avg_launch_us.
 
   python3 tools/kernel_trace_stats.py <dir with *kernel_trace.csv> <out.csv> --prime 300 --warmup 10 --steps 50
@@ -26,7 +27,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--guard", type=int, default=1, help="steps before the priming (bench.py's parity guard)")
+    ap.add_argument("--settle-from", default=None, help="log holding the run's JSON line: its config.settle_ms_per_step "
+                    "blocks (200 untimed steps each, behind the priming) are skipped too")
     a = ap.parse_args()
+    settle = 0
+    if a.settle_from:
+        import json
+        lines = [ln for ln in open(a.settle_from) if ln.startswith('{"metric')]
+        if lines:
+            settle = 200 * len(json.loads(lines[-1]).get("config", {}).get("settle_ms_per_step", []))
     files = glob.glob(os.path.join(a.src, "**", "*kernel_trace.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no *kernel_trace.csv under {a.src}")
@@ -34,7 +43,7 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-    lo = a.guard + a.prime + a.warmup
+    lo = a.guard + a.prime + settle + a.warmup
     rows = []
     for k, v in per.items():
         v.sort()
