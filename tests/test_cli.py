@@ -291,7 +291,8 @@ def test_script_with_parser_pool_is_quiet_and_complete(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "NanoReviser.py"), "-d", str(d), "-o", out, "-S", "ecoli",
                         "--thread", "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert r.stderr.strip() == "", r.stderr
+    noise = [ln for ln in r.stderr.splitlines() if ln.strip() and "amdgpu.ids" not in ln]   # (libdrm's note on some boxes)
+    assert noise == [], r.stderr
     ref = str(tmp_path) + "/ref/"
     assert cli.main(["-d", FAST5, "-o", ref, "-S", "ecoli", "--gpus", "1"]) == 0
     by_kind = {os.path.basename(src[0]).split(".")[0]: "A", os.path.basename(src[1]).split(".")[0]: "B"}
