@@ -331,13 +331,23 @@ def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
     os.replace(tmp, dst)
 
 
+def parser_pool_size(threads: int, cores: int, gpu_workers: int, n_files: int) -> int:
+    """Parser processes of ONE GPU worker: --thread, capped at this worker's share of the cores the process may use
+    (cores // gpu_workers, at least 1), at 32 and at the number of files."""
+    share = max(1, cores // max(1, gpu_workers))
+    return max(1, min(int(threads), share, 32, max(1, n_files)))
+
+
 def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None],
-                  on_file: Optional[Callable[[str, bool], None]] = None) -> dict:
+                  on_file: Optional[Callable[[str, bool], None]] = None, gpu_workers: int = 1) -> dict:
     """Revise `files` (names inside args.fast5_base_dir) with one engine.  The host stage (HDF5
     parsing, event collapse, signal segmentation) runs in worker PROCESSES (--thread of them, capped
     at the core count) that stay a bounded number of reads ahead of the device.
     on_file(fn, revised): called once per file when its output is final (revised, or the original
-    basecalls after a failure; revised=False also for files that could not be parsed at all)."""
+    basecalls after a failure; revised=False also for files that could not be parsed at all).
+    gpu_workers: how many such calls run on this host at the same time (one per GPU, `run_workers`): the cores are
+    SHARED, so each call's parser pool gets usable_cores() // gpu_workers of them - eight workers on a 16-core cgroup
+    start 8 x 2 parser processes, not 8 x 16."""
     stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
     # NRV_CLI_TRACE=1: where the wall time of this call goes (first device call, engine idle gaps, tail), to the log
     trace, t_start = ([] if os.environ.get("NRV_CLI_TRACE") else None), time.perf_counter()
@@ -372,7 +382,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         free.put(reviser)
         engines.append(reviser)
     stats_lock = threading.Lock()
-    nworkers = max(1, min(int(args.thread), usable_cores(), 32, max(1, len(files))))
+    nworkers = parser_pool_size(int(args.thread), usable_cores(), gpu_workers, len(files))
+    stats["parser_workers"] = nworkers
     jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup)
             for fn in files]
 
@@ -604,10 +615,11 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         collect_finished(True)
         if pool is not None:                          # all work is in: an orderly end of the workers (their queues' semaphores
             pool.shutdown(wait=True)                  # are released here, not left to the resource tracker)
-    if trace:
+    calls = sorted((c for c in trace if c[0] == "call"), key=lambda c: c[1]) if trace else []
+    if trace and not calls:                           # every file failed before a device call: only the marks
+        log("[trace] " + "; ".join(f"{w} {t:.3f} s" for k, t, w in trace if k == "mark") + "; no device call")
+    if calls:
         t_end = time.perf_counter() - t_start
-        calls = [c for c in trace if c[0] == "call"]
-        calls.sort(key=lambda c: c[1])
         busy, idle, end = sum(c[2] for c in calls), 0.0, calls[0][1]
         for _, t, d in calls:                         # time with NO engine inside a call, between the first and the last call
             idle += max(0.0, t - end)
@@ -636,7 +648,8 @@ def _worker(rank: int, world: int, args, files: List[str], q, factory=None):
     becomes final, so that the parent knows exactly which files are done should this process die."""
     try:
         rv = (factory or _default_factory)(args, rank)
-        st = process_files(args, files, rv, print, on_file=lambda fn, ok: q.put(("file", rank, fn, bool(ok))))
+        st = process_files(args, files, rv, print, on_file=lambda fn, ok: q.put(("file", rank, fn, bool(ok))),
+                           gpu_workers=world)
         rv.close()
         q.put(("done", rank, st, None))
     except BaseException as e:           # engine could not be created: loud, no silent fallback

@@ -12,6 +12,14 @@
 
 using namespace nrv;
 
+// -DNRV_DEV_FAST (tools/lstm_exp.sh D:...): a development build of the f16x2 mode with hard_sigmoid only - a quarter
+// of the compile time; the other precision modes and recurrent_act = 1 launch nothing there.  Never the product.
+#ifdef NRV_DEV_FAST
+#define NRV_ACT1(...)
+#else
+#define NRV_ACT1(...) __VA_ARGS__
+#endif
+
 namespace {
 
 thread_local std::string g_create_error = "";
@@ -719,9 +727,22 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
         std::vector<float> f2(fr.size() / 2);
         memcpy(f2.data(), fr.data(), fr.size() * 2);
         d.cr_w2 = put(f2.data(), f2.size());
-        float e2[24];
+        float e2[25];
         NRV_FOR (int co = 0; co < 8; ++co) { e2[co] = ep[co]; e2[8 + co] = ep[16 + co]; e2[16 + co] = ep[32 + co]; }
-        d.cr_ep = put(e2, 24);
+        // Range guard of conv1's output (kept x 2^6 as an f16 pair: |c1| must stay below 65504 / 64): a STATIC bound on
+        // the samples.  |c1[o]| <= |s1[o]| (|b1[o]| + sum_k |w1[k][o]| xmax) + |h1[o]|, so with every |x| <= xlim no
+        // conv1 output can leave the f16 range; a unit that sees a larger sample counts as out of range (re-run in f32).
+        {
+          const float* c0u = host.data() + d.conv;             // w1 24, b1 8, s1 8 (BatchNorm scale), h1 8 (shift)
+          double xl = 1e30;
+          NRV_FOR (int o = 0; o < 8; ++o) {
+            const double sw = std::fabs((double)c0u[o]) + std::fabs((double)c0u[8 + o]) + std::fabs((double)c0u[16 + o]);
+            const double sc = std::fabs((double)c0u[32 + o]), room = 1000.0 - std::fabs((double)c0u[40 + o]);
+            if (sc > 0 && sw > 0) { const double l = (room / sc - std::fabs((double)c0u[24 + o])) / sw; if (l < xl) xl = l; }
+          }
+          e2[24] = (float)(xl > 0 ? xl : 0.0);
+        }
+        d.cr_ep = put(e2, 25);
         // dense 400 -> 64 x 2^10 as A fragments in the k order the conv2 result tiles arrive in:
         // [ks 13][mt 4][term 2][64 lanes][8 f16]; lane (m = l & 15, kg = l >> 4), element j:
         //   position 4 ks + 2 (j >> 2) + (kg >> 1), channel 4 (kg & 1) + (j & 3), output feature 16 mt + m
@@ -960,11 +981,15 @@ template <int KQ0, int KQ1, int H, int R, int WR>
 static void launch_lstm_f32(nrv_handle* h, const LstmArgs& a, int tiles) {
   constexpr int NG = (H + 31) / 32;
   static_assert(NG * WR <= 4, "at most 4 waves per workgroup (one per SIMD, 512 registers each)");
+#ifdef NRV_DEV_FAST
+  return;
+#else
   LstmArgs la = a;
   la.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(la.n_blk)), blk(64 * NG * WR);
   if (h->act == 0) hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, R, WR, false, 0>), grid, blk, 0, h->stream, la);
-  else hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, R, WR, false, 1>), grid, blk, 0, h->stream, la);
+  NRV_ACT1(else hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, R, WR, false, 1>), grid, blk, 0, h->stream, la);)
+#endif
 }
 
 #ifdef NRV_EXPERIMENTS
@@ -1000,6 +1025,9 @@ static void launch_lstm(nrv_handle* h, const LstmArgs& a, int tiles, int geo) {
 template <int KQ0, int KQ1, int H, int R, int WR>
 static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* const ws[2], int tiles) {
   constexpr int NG = (H + 31) / 32;
+#ifdef NRV_DEV_FAST
+  return;
+#else
   LstmSplitArgs sa;
   sa.T = a.T; sa.n_rows = a.n_rows;
   for (int m = 0; m < 2; ++m)
@@ -1018,7 +1046,7 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
 #endif
     {
       if (h->act == 0) hipLaunchKernelGGL((lstm_pair_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);
-      else hipLaunchKernelGGL((lstm_pair_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
+      NRV_ACT1(else hipLaunchKernelGGL((lstm_pair_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);)
       return;
     }
   }
@@ -1027,8 +1055,9 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
 #endif
   {
     if (h->act == 0) hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);
-    else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);
+    NRV_ACT1(else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);)
   }
+#endif
 }
 
 template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int NBG, int NA, int GPT = 1, int KBL = 0>
@@ -1051,7 +1080,7 @@ static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], co
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
   if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
+  NRV_ACT1(else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);)
 }
 
 template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA, int KBL = 0, bool RAW = false>
@@ -1070,7 +1099,7 @@ static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], c
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
   if (h->act == 0) hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 0, NBG, NA, KBL, RAW>), grid, blk, 0, h->stream, sa);
-  else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA, KBL, RAW>), grid, blk, 0, h->stream, sa);
+  NRV_ACT1(else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA, KBL, RAW>), grid, blk, 0, h->stream, sa);)
 }
 
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
@@ -1163,7 +1192,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         int gx = wgc > wgr ? wgc : wgr;
         gx = gx < 128 ? (gx + 1) & ~1 : 128;
         if (h->act == 0) hipLaunchKernelGGL((cnn_r_kernel<0, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);
-        else hipLaunchKernelGGL((cnn_r_kernel<1, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);
+        NRV_ACT1(else hipLaunchKernelGGL((cnn_r_kernel<1, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);)
         h2_fused_l1 = h2_fused_l2 = true;
       }
 #endif
@@ -1174,7 +1203,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       const int wg = wg_c > wg_l ? wg_c : wg_l;
       if (h2_fused_l2) {}
       else if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
-      else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
+      NRV_ACT1(else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);)
       h2_fused_l1 = true;
     } else {
       CnnArgs a;
@@ -1183,8 +1212,10 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         a.m[m] = CnnModelParams{d.all + d.conv, d.all + d.dpack, d.all + d.dbias, d.all + d.dsplit, h->S[m]};
       }
       a.signal = d_sig; a.T = Tc; a.n_rows = n_rows; a.n_tiles = n_tiles;
+#ifndef NRV_DEV_FAST
       if (h->split & 32) hipLaunchKernelGGL(cnn_kernel<true>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
       else hipLaunchKernelGGL(cnn_kernel<false>, dim3(blocks, 2), dim3(kCnnThreads), 0, h->stream, a);
+#endif
     }
     if ((rc = mark(1))) return rc;
   }
@@ -1214,9 +1245,9 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       dim3 grid((n + 63) / 64, 2, 2);
       if (h->h2) {
         if (h->act == 0) hipLaunchKernelGGL((lstm1_kernel<0, true>), grid, dim3(256), 0, h->stream, a1);
-        else hipLaunchKernelGGL((lstm1_kernel<1, true>), grid, dim3(256), 0, h->stream, a1);
+        NRV_ACT1(else hipLaunchKernelGGL((lstm1_kernel<1, true>), grid, dim3(256), 0, h->stream, a1);)
       } else if (h->act == 0) hipLaunchKernelGGL(lstm1_kernel<0>, grid, dim3(256), 0, h->stream, a1);
-      else hipLaunchKernelGGL(lstm1_kernel<1>, grid, dim3(256), 0, h->stream, a1);
+      NRV_ACT1(else hipLaunchKernelGGL(lstm1_kernel<1>, grid, dim3(256), 0, h->stream, a1);)
     }
     if ((rc = mark(2))) return rc;
     for (int m = 0; m < 2; ++m) {
@@ -1242,7 +1273,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       }
       dim3 grid((n + 63) / 64, 2, 2);
       if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
-      else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);
+      NRV_ACT1(else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);)
     }
 #ifdef NRV_EXPERIMENTS
     else if (h->h2) {
@@ -1361,11 +1392,15 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         sa.m[m] = HeadSplitModelParams{d.all + d.h_ws, d.all + d.h_wb, h->X2[m], h->MO[m]};
       }
       const int blocks = sa.n_units < 512 ? (sa.n_units + 3) / 4 : 128;    // persistent: one per CU and model
+#ifndef NRV_DEV_FAST
       hipLaunchKernelGGL(head_mlp_split_kernel, dim3(blocks, 2), dim3(256), 0, h->stream, sa);
     } else {
       hipLaunchKernelGGL(head_mlp_kernel, dim3(tiles * T, 2), dim3(64), 0, h->stream, a);
+#endif
     }
+#ifndef NRV_DEV_FAST
     hipLaunchKernelGGL(head_final_kernel, dim3(tiles, 2), dim3(256), 0, h->stream, a);
+#endif
     if ((rc = mark(6))) return rc;
   }
   HIPCHK(h, hipGetLastError());
@@ -1892,21 +1927,32 @@ int nrv_prof_overhead(nrv_handle* h, double* us) {
   if (!us) { h->err = "nrv_prof_overhead: null output"; return NRV_E_INVALID; }
   // what a bracket measures beyond the kernel it encloses: two event records back to back on the launch stream
   constexpr int N = 64;
-  hipEvent_t ev[2 * N];
-  for (int i = 0; i < 2 * N; ++i) HIPCHK(h, hipEventCreate(&ev[i]));
+  struct Events {                                    // destroyed on every path out of this function
+    hipEvent_t ev[2 * N];
+    int n = 0;
+    ~Events() { for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]); }
+  } E;
+  for (; E.n < 2 * N; ++E.n) HIPCHK(h, hipEventCreate(&E.ev[E.n]));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (int i = 0; i < 2 * N; ++i) HIPCHK(h, hipEventRecord(ev[i], h->stream));
+  for (int i = 0; i < 2 * N; ++i) HIPCHK(h, hipEventRecord(E.ev[i], h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   double tot = 0;
   for (int i = 0; i < N; ++i) {
     float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    HIPCHK(h, hipEventElapsedTime(&ms, E.ev[2 * i], E.ev[2 * i + 1]));
     tot += ms;
   }
-  for (int i = 0; i < 2 * N; ++i) (void)hipEventDestroy(ev[i]);
   *us = tot / N * 1e3;
   return NRV_OK;
 }
+
+#if NRV_STAMP
+// diagnostic build only (not in include/nanorev.h): the phase stamps of the last lstm_h2s_kernel launches
+int nrv_exp_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(nrv::nrv_stamp_buf)) bytes = sizeof(nrv::nrv_stamp_buf);
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(nrv::nrv_stamp_buf), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? (int)0 : -1;
+}
+#endif
 
 const char* nrv_kernel_name(int slot) {
   // slots are pipeline stages; which kernel runs a stage depends on nrv_set_precision

@@ -51,7 +51,8 @@ struct CnnRConsts {        // per model, BY VALUE in the kernel arguments: scala
 };
 struct CnnRModelParams {
   const void* w2frag;      // conv2 A operand x 2^u: [term 2][64 lanes][8 f16] (two-position form, see above)
-  const float* ep;         // [3][8]: accumulator init b2 x 2^(6+u), k1 = s2 x 2^-u, k2 = h2 x 2^6 per output channel
+  const float* ep;         // [3][8]: accumulator init b2 x 2^(6+u), k1 = s2 x 2^-u, k2 = h2 x 2^6 per output channel;
+                           // [24]: the sample magnitude below which no conv1 output can leave the f16 range (range guard)
   const void* dfrag;       // dense A operand x 2^10: [ks 13][mt 4][term 2][64 lanes][8 f16]
   const float* dbias;      // [64] x 2^16
   float* out;              // S x 2^6 as f16 split planes: window-major [wtile][t][16 chunks][32][8 f16] or event-major
@@ -216,7 +217,13 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
 #endif
   // conv1 + BatchNorm of one position (this lane's event) from its three samples -> ring slot d, both terms.
   // (Written as packed f32 math, v_pk_fma_f32, it was measured SLOWER, 73 vs 67 us.)
+  // Range guard of c1: a conv1 output beyond 65504 / 2^6 would become hi = +inf, lo = -inf, their products
+  // NaN, and the ReLU behind conv2 (v_med3) turns a NaN into 0 - a silently wrong feature that the check on S cannot
+  // see.  So the centre samples (every position of the window is one lane's centre sample exactly once) feed a running
+  // maximum, one v_med3_f32 each, which is compared once per unit with the static bound of upload_model (ep[24]).
+  float xmax = 0.f;
   auto conv1_store = [&](lds_h* d, float xm, float xc, float xp) __attribute__((always_inline)) {
+    xmax = __builtin_amdgcn_fmed3f(__builtin_fabsf(xc), xmax, 3.0e38f);
     float c[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
@@ -404,6 +411,7 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     }
     wave_lds_fence();                                  // the next unit overwrites the ring
   }
+  bad |= !(xmax <= P.ep[24]);
   if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(args.sat, 1u);
 }
 

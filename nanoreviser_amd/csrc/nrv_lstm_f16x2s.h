@@ -28,6 +28,28 @@ namespace nrv {
 // VALU instruction is not free (two per 16-cycle tick), and the split of 8 values per (row tile, k-block) and
 // lane was 40 % of the kernel's VALU instructions.  The copy-out adds hi + lo back before the BatchNorm.
 // ---------------------------------------------------------------------------------------
+// Diagnostic build only (-DNRV_STAMP=1, tools/lstm_exp.sh stamp; no stamp executes in the product): s_memtime at the
+// phase edges of every step and wave, kept in LDS during the launch and copied at its end to a buffer of their own
+// that nothing else reads (scripts/gpu_stamps.py reads it through nrv_exp_stamps).  The data, and with it the clock,
+// are the product's; the stamps' fences forbid some overlap, so read SHARES of a step, not its length.
+#ifndef NRV_STAMP
+#define NRV_STAMP 0
+#endif
+#if NRV_STAMP
+constexpr int kStampSlots = 32, kStampSteps = 15, kStampWaves = 4, kStampBlocks = 256;
+__device__ unsigned long long nrv_stamp_buf[2][kStampBlocks][kStampWaves][kStampSteps][kStampSlots];
+#define NRV_STAMP_AT(slot)                                                                                   \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                               \
+    stamp_lds[(wave * kStampSteps + stamp_step) * kStampSlots + (slot)] = t_;                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+#else
+#define NRV_STAMP_AT(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x4 mfma16_f16(const f16x8& a, const f16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -66,6 +88,13 @@ lstm_h2s_kernel(const LstmH2Args args) {
 #endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if NRV_STAMP
+  __shared__ unsigned long long stamp_lds[kStampWaves * kStampSteps * kStampSlots];
+  int stamp_step = 0;
+  for (int i = threadIdx.x; i < kStampWaves * kStampSteps * kStampSlots; i += 64 * (H / (16 * UH)) * WR) stamp_lds[i] = 0;
+  unsigned long long stamp_rt0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_rt0)::"memory");
+#endif
   const int hg = wave % NG, wr = wave / NG;
   const int l15 = lane & 15, kq = lane >> 4;
   const LstmBlock blk = lstm_block();
@@ -284,14 +313,10 @@ lstm_h2s_kernel(const LstmH2Args args) {
     constexpr bool WORK = decltype(work_tag)::value;
     GateSt gs;
     CopySt cs;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int uh = 0; uh < UH; ++uh)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) N[g][uh][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (N is not zeroed: the first product of every tile takes a constant 0 as its C operand)
 #pragma unroll
     for (int kk = 0; kk < KK_IN; ++kk) {
+      if constexpr (WORK) NRV_STAMP_AT(8 + kk);
       {
         const int ka = kk + LA;                          // activations LA blocks ahead: input, then recurrent
 #pragma unroll
@@ -311,7 +336,8 @@ lstm_h2s_kernel(const LstmH2Args args) {
 #pragma unroll
           for (int pr = 0; pr < 3; ++pr) {
             const int tk = (e * RT + rt) * 3 + pr;
-            N[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]], N[g][uh][rt]);
+            N[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]],
+                                      (kk == 0 && pr == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : N[g][uh][rt]);
             if constexpr (WORK) {
               if (tk < TG) {
 #pragma unroll
@@ -328,7 +354,11 @@ lstm_h2s_kernel(const LstmH2Args args) {
                   copy_stage(cs, himg_w, t_out, pc / CST, pc % CST);
               }
               __builtin_amdgcn_sched_barrier(0);
-              if (tk == TG - 1) __syncthreads();         // h_s complete: rec(s+1) operands and the copy-out may read it
+              if (tk == TG - 1) {
+                NRV_STAMP_AT(24);
+                __syncthreads();                         // h_s complete: rec(s+1) operands and the copy-out may read it
+                NRV_STAMP_AT(25);
+              }
             }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -340,6 +370,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
 #pragma unroll
     for (int kr = 0; kr < KK_REC; ++kr) {
       const int kk = KK_IN + kr;
+      NRV_STAMP_AT(1 + kr);
       {
         const int ka = kk + LA;
 #pragma unroll
@@ -378,36 +409,72 @@ lstm_h2s_kernel(const LstmH2Args args) {
       for (int rt = 0; rt < RT; ++rt) loadA_in(x0, i, rt, a[i][rt]);
     in_phase(std::false_type{}, Z, Z, x0, nullptr, nullptr, 0, x1);
   }
+  // The steps 0 .. T - 2 (rec, then in() of the next step with this step's gates between its products) are the loop;
+  // the LAST step (rec, plain gates, copy-out) stands behind it.  As two arms of one `if` inside the loop (r02-r03)
+  // LLVM hoisted what both arms begin with - the read-out of Z and the hard_sigmoids of ALL 32 gate elements, 230
+  // vector instructions - in front of the branch, i.e. behind rec()'s last product with nothing to hide behind, and
+  // in()'s 128 accumulator-zeroing moves came on top: in-kernel stamps (scripts/gpu_stamps.py, r04a) put 1500 of a
+  // step's 23.6 k cycles there.
+  auto last_step = [&](int s) __attribute__((always_inline)) {
+    NRV_STAMP_AT(26);
+    // no input projection to hide behind: plain gates, barrier, copy-out
+    GateSt gs;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+#pragma unroll
+      for (int st = 0; st < GST; ++st) gate_stage(gs, Z, himg(s) + hw_off, e, st);
+      if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    CopySt cs;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+      for (int st = 0; st < CST; ++st) copy_stage(cs, himg(s), t_of(s), i, st);
+    NRV_STAMP_AT(27);
+  };
 #pragma unroll 1
-  for (int s = 0; s < T; ++s) {
+  for (int s = 0; s + 1 < T; ++s) {
     // step s: Z holds x_s W on entry; on exit it holds x_{s+1} W and h_s has been written out
+#if NRV_STAMP
+    stamp_step = s;
+#endif
+    NRV_STAMP_AT(0);
     const ABase xn = mk_base(s + 1);
     if (s > 0) rec_phase(Z, himg(s - 1) + hp_off, xn);
-    if (s + 1 < T) {
-      in_phase(std::true_type{}, N, Z, xn, himg(s) + hp_off, himg(s), t_of(s), xn);
+    in_phase(std::true_type{}, N, Z, xn, himg(s) + hp_off, himg(s), t_of(s), xn);
+    NRV_STAMP_AT(26);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int uh = 0; uh < UH; ++uh)
+      for (int uh = 0; uh < UH; ++uh)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) Z[g][uh][rt] = N[g][uh][rt];
-    } else {
-      // the last step has no input projection to hide behind: plain gates, barrier, copy-out
-      GateSt gs;
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-#pragma unroll
-        for (int st = 0; st < GST; ++st) gate_stage(gs, Z, himg(s) + hw_off, e, st);
-        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-      CopySt cs;
-#pragma unroll
-      for (int i = 0; i < NIT; ++i)
-#pragma unroll
-        for (int st = 0; st < CST; ++st) copy_stage(cs, himg(s), t_of(s), i, st);
-    }
+        for (int rt = 0; rt < RT; ++rt) Z[g][uh][rt] = N[g][uh][rt];
+    NRV_STAMP_AT(27);
   }
+  {
+    const int s = T - 1;
+#if NRV_STAMP
+    stamp_step = s;
+#endif
+    NRV_STAMP_AT(0);
+    const ABase xn = mk_base(s + 1);
+    if (s > 0) rec_phase(Z, himg(s - 1) + hp_off, xn);
+    last_step(s);
+  }
+#if NRV_STAMP
+  {
+    unsigned long long stamp_rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_rt1)::"memory");
+    stamp_step = kStampSteps - 1;
+    stamp_lds[(wave * kStampSteps + stamp_step) * kStampSlots + 0] = stamp_rt0;
+    stamp_lds[(wave * kStampSteps + stamp_step) * kStampSlots + 1] = stamp_rt1;
+    __syncthreads();
+    if (blockIdx.x < kStampBlocks)
+      for (int i = threadIdx.x; i < kStampWaves * kStampSteps * kStampSlots; i += NTHREADS)
+        (&nrv_stamp_buf[H == 128 ? 0 : 1][blockIdx.x][0][0][0])[i] = stamp_lds[i];
+  }
+#endif
 #if NRV_EXP & 64
   if (blockIdx.x == 3 && threadIdx.x == 0 && ((NRV_EXP & 256) ? (H == 64 && KQ0 == 8) : (NRV_EXP & 128) ? (H == 64 && KQ0 == 64) : H == 128))
     printf("CLK %llu %llu\n", (unsigned long long)(clock64() - exp_c0), (unsigned long long)(wall_clock64() - exp_w0));

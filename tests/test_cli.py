@@ -109,6 +109,38 @@ def test_broken_fast5_is_logged_not_fatal(tmp_path):
     assert not glob.glob(out + "*_out.fasta")
 
 
+def test_parser_pool_is_a_share_of_the_cores_per_gpu_worker(tmp_path, monkeypatch):
+    """eight GPU workers on a 16-core cgroup must start 8 x 2 parser processes, not 8 x 16."""
+    assert cli.parser_pool_size(100, 16, 1, 4000) == 16
+    assert cli.parser_pool_size(100, 16, 8, 4000) == 2
+    assert cli.parser_pool_size(100, 16, 32, 4000) == 1            # never zero
+    assert cli.parser_pool_size(4, 256, 8, 4000) == 4              # --thread still caps it
+    assert cli.parser_pool_size(100, 256, 2, 4000) == 32           # ... and so does 32
+    assert cli.parser_pool_size(100, 16, 1, 3) == 3
+    assert 8 * cli.parser_pool_size(100, 16, 8, 4000) <= 16
+    # through the real call: process_files reports the pool it used
+    monkeypatch.setattr(cli, "usable_cores", lambda: 6)
+    args = cli.get_args(["-d", FAST5, "-o", str(tmp_path) + "/o/", "-S", "ecoli"])
+    os.makedirs(args.output_dir, exist_ok=True)
+    st = cli.process_files(args, sorted(os.listdir(FAST5)), EchoEngine(), lambda m: None, gpu_workers=3)
+    assert st["parser_workers"] == 2 and st["reads"] == 2
+
+
+def test_trace_summary_survives_a_run_without_device_calls(tmp_path, monkeypatch):
+    """with NRV_CLI_TRACE=1 and no device call at all (every file unparsable) the summary used to index
+    calls[0]; the failed reads must still come back."""
+    monkeypatch.setenv("NRV_CLI_TRACE", "1")
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "broken.fast5").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\x00" * 64)
+    out = str(tmp_path) + "/o/"
+    logged = []
+    args = cli.get_args(["-d", str(d), "-o", out, "-S", "ecoli"])
+    os.makedirs(out, exist_ok=True)
+    st = cli.process_files(args, ["broken.fast5"], EchoEngine(), logged.append)
+    assert st["failed"] == ["broken.fast5"] and any("no device call" in m for m in logged)
+
+
 def _orig(fn):
     _, rd, _ = load_read("_".join(fn.split("_")[-3:-1]))
     return "".join(b.decode() for b in rd.bases.tolist())

@@ -27,6 +27,78 @@ def _fixture_windows(reads, key="ch10_read5252", lo=1000, n=320, T=11):
     return np.ascontiguousarray(sw[lo:lo + n]), np.ascontiguousarray(fw[lo:lo + n])
 
 
+def _conv1_sample_bound(m):
+    """The engine's static bound (nrv_api.hip upload_model, cnn_r_kernel's ep[24]): below it no conv1 + BatchNorm
+    output can leave the f16 range of the f16x2 signal branch (|c1| x 2^6 <= 65504)."""
+    w, b, g, be, mu, var = [np.asarray(x, np.float64) for x in m.tensors[:6]]
+    inv = g / np.sqrt(var + 1e-3)
+    sh = be - mu * inv
+    return float((((1000.0 - np.abs(sh)) / np.abs(inv) - np.abs(b)) / np.abs(w[:, 0, :]).sum(0)).min())
+
+
+@pytest.mark.parametrize("sp", ["ecoli", "human"])
+@pytest.mark.parametrize("spike", [150.0, 300.0, 600.0, 1000.0])
+def test_isolated_spikes_in_the_conv1_overflow_band(reads, species_models, sp, spike):
+    """ONE isolated sample of 150 ... 1000 normalised units (an ADC-saturated spike: (32767 - median) /
+    MAD) overflows conv1 + BatchNorm's f16 pair (gain 5 - 11, kept x 2^6) while S itself stays in range - the guard on
+    S alone let such a window through with zeroed conv2 features.  Now a sample beyond the static bound trips the
+    guard: the stage is re-run on the f32 kernels (bit-identical to the f32 mode) whenever a spike exceeds the bound,
+    and every result meets the parity policy against fp64 either way."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models[sp]
+    sw, fw = _fixture_windows(reads, n=256)
+    sw = sw.copy()
+    rng = np.random.default_rng(int(spike))
+    hit = rng.choice(256, 24, replace=False)
+    for w in hit:
+        sw[w, rng.integers(11), rng.integers(50)] = np.float32(spike) * (1 if rng.integers(2) else -1)
+    bound = min(_conv1_sample_bound(m1), _conv1_sample_bound(m2))
+    rv = Reviser(m1, m2, precision="f16x2")
+    got = rv.predict_pair(sw, fw)
+    _, reruns = rv.saturated()
+    rv.set_precision("f32")
+    ref32 = rv.predict_pair(sw, fw)
+    rv.close()
+    print(f"SPIKE {sp} {spike:g}: bound {bound:.1f} reruns {reruns}")
+    if spike > 1.001 * bound:
+        assert reruns == 1
+        for g, r in zip(got, ref32):
+            assert np.array_equal(g, r)
+    elif spike < 0.999 * bound:
+        assert reruns == 0
+    q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sw, fw, np.float64)
+    nf1, nf2 = f32_floor(m1, m2, sw, fw, q1, q2)
+    check_vs_fp64(got[0], got[2], q1, nf1, f"spike {spike:g} m1", max_ill=0.05)
+    check_vs_fp64(got[1], got[3], q2, nf2, f"spike {spike:g} m2", max_ill=0.05)
+
+
+@pytest.mark.parametrize("amp", [20.0, 40.0, 60.0])
+def test_whole_windows_in_the_conv1_overflow_band(reads, species_models, amp):
+    """Whole windows at 20 ... 60 x the fixture amplitude (|x| up to 170 ... 500): between the 10x case (nothing leaves
+    the range) and the 100x case (S itself overflows).  Policy against fp64; re-run => the f32 mode's bits."""
+    from nanoreviser_amd.engine import Reviser
+    from oracle import nrv_oracle as O
+    m1, m2 = species_models["human"]
+    sw, fw = _fixture_windows(reads, n=256)
+    sig = (sw * np.float32(amp)).astype(np.float32)
+    rv = Reviser(m1, m2, precision="f16x2")
+    got = rv.predict_pair(sig, fw)
+    _, reruns = rv.saturated()
+    rv.set_precision("f32")
+    ref32 = rv.predict_pair(sig, fw)
+    rv.close()
+    bound = min(_conv1_sample_bound(m1), _conv1_sample_bound(m2))
+    assert reruns == (1 if float(np.abs(sig).max()) > bound else 0)
+    if reruns:
+        for g, r in zip(got, ref32):
+            assert np.array_equal(g, r)
+    q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sig, fw, np.float64)
+    nf1, nf2 = f32_floor(m1, m2, sig, fw, q1, q2)
+    check_vs_fp64(got[0], got[2], q1, nf1, f"x{amp:g} m1", max_ill=0.05)
+    check_vs_fp64(got[1], got[3], q2, nf2, f"x{amp:g} m2", max_ill=0.05)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("amp", [10.0, 100.0, 1000.0])
 def test_amplified_signal_vs_fp64_oracle(reads, species_models, mode, amp):

@@ -12,6 +12,13 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DNR
 for v in "$@"; do
   if [ "$v" = knobs ]; then
     ( /opt/rocm/bin/hipcc $FLAGS -o exp/libnanorev_hip_experiments.so nrv_api.hip > exp/build_knobs.log 2>&1; echo "knobs rc=$?" ) &
+  elif [ "$v" = stamp ]; then
+    # product kernels + s_memtime stamps at the phase edges of lstm_h2s_kernel (scripts/gpu_stamps.py)
+    ( /opt/rocm/bin/hipcc ${FLAGS/-DNRV_EXPERIMENTS=1/} -DNRV_STAMP=1 $EXTRA -o exp/libnanorev_hip_stamp.so nrv_api.hip > exp/build_stamp.log 2>&1; echo "stamp rc=$?" ) &
+  elif [[ "$v" == D:* ]]; then
+    # product kernels with extra -D flags: tools/lstm_exp.sh D:name:-DNRV_X=1,-DNRV_Y=2 -> exp/libnanorev_hip_name.so
+    IFS=: read -r _ name defs <<< "$v"
+    ( /opt/rocm/bin/hipcc ${FLAGS/-DNRV_EXPERIMENTS=1/} ${defs//,/ } -o exp/libnanorev_hip_$name.so nrv_api.hip > exp/build_$name.log 2>&1; echo "$name rc=$?" ) &
   else
     ( /opt/rocm/bin/hipcc $FLAGS -DNRV_EXP=$v -o exp/libnanorev_hip_exp$v.so nrv_api.hip > exp/build$v.log 2>&1; echo "exp$v rc=$?" ) &
   fi
