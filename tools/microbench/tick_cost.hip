@@ -9,7 +9,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { S_NONE, S_FMA1, S_FMA2, S_FMA3, S_EXP1, S_EXP_FMA, S_SMOV1, S_SMOV2, S_DSW, S_DSR, S_LOAD12, S_LOAD12_SMOV, S_ACCRD, S_NOP1, S_CVT, S_EXP_RCP, S_FMA4, S_FMA_FIRST, S_ALOAD, S_ALOAD_FMA2, S_ADSR, S_ADSW, S_AACC, S_ALOAD4, S_ASTORE, S_ABUF, S_ADSR64, S_ADSW32, S_ADSW64, S_ADSW128, S_ADSR2, S_ABUF1, S_ADSW16_4, S_WAITONLY, S_ABUF_NOWAIT, S_ADSR_NOWAIT, S_ABUF_SPREAD, S_ABUF_MID, S_ADSW64_NOW, S_ABUF8 };
+enum { S_NONE, S_FMA1, S_FMA2, S_FMA3, S_EXP1, S_EXP_FMA, S_SMOV1, S_SMOV2, S_DSW, S_DSR, S_LOAD12, S_LOAD12_SMOV, S_ACCRD, S_NOP1, S_CVT, S_EXP_RCP, S_FMA4, S_FMA_FIRST, S_ALOAD, S_ALOAD_FMA2, S_ADSR, S_ADSW, S_AACC, S_ALOAD4, S_ASTORE, S_ABUF, S_ADSR64, S_ADSW32, S_ADSW64, S_ADSW128, S_ADSR2, S_ABUF1, S_ADSW16_4, S_WAITONLY, S_ABUF_NOWAIT, S_ADSR_NOWAIT, S_ABUF_SPREAD, S_ABUF_MID, S_ADSW64_NOW, S_ABUF8, S_P_WAIT_IN, S_P_2LD_SAME, S_P_DSR_IN, S_P_DSW_IN, S_P_DSW_EDGE, S_P_FMA_IN, S_P_ACC_IN, S_P_ST_IN, S_P_ENTRY_OLD, S_P_ENTRY_NEW, S_P_ENTRY_NEW2, S_P_EXP_IN, S_P_EXP_EDGE, S_P_LD_LAST, S_P_ENTRY_NEW3 };
 
 template <int SIDE, int CH, int NACC = 8>
 __global__ void __launch_bounds__(256) k(float* out, const f32x4* __restrict__ src, int iters, unsigned seed,
@@ -154,6 +154,44 @@ __global__ void __launch_bounds__(256) k(float* out, const f32x4* __restrict__ s
             if constexpr (SIDE == S_ABUF_SPREAD) T12X(BL0, "", "", BL1, "");
             else T12X("", BL0, "", "", BL1);
           }
+          // placement forms: P(i) is what stands BEHIND MFMA i of the 12 (chains of three: 0-2, 3-5, 6-8, 9-11; so
+          // i % 3 == 0, 1 are INSIDE a chain - the next MFMA depends on this one -, i % 3 == 2 is a chain edge)
+#define T12P(P0, P1, P2, P3, P4, P5, P6, P7, P8, P9, P10, P11)                                                      \
+  asm volatile(MFB("%0") P0 MFB("%0") P1 MFB("%0") P2 MFB("%1") P3 MFB("%1") P4 MFB("%1") P5 MFB("%2") P6 MFB("%2") P7 MFB("%2") P8 MFB("%3") P9 MFB("%3") P10 MFB("%3") P11 \
+               : "+a"(acc[(m / 12 * 4) % NACC]), "+a"(acc[(m / 12 * 4 + 1) % NACC]), "+a"(acc[(m / 12 * 4 + 2) % NACC]),          \
+                 "+a"(acc[(m / 12 * 4 + 3) % NACC]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+s"(sc),                \
+                 "+v"(ld[0]), "+v"(ld[1]), "+v"(ld2)                                                                              \
+               : "v"(a[(m / 12) & 3]), "v"(b[(m / 4) & 3]), "v"(v1), "v"(gp), "v"(ldsa), "v"(hv), "v"(boff), "s"(rsrc), "s"(goff) \
+               : "memory")
+#define WT "s_waitcnt vmcnt(14)\n\t"
+#define DR "ds_read_b128 %9, %16\n\t"
+#define DW "ds_write_b16 %16, %17\n\t"
+#define AR "v_accvgpr_read_b32 %4, a100\n\t"
+#define ST "global_store_dwordx4 %15, %9, off offset:2048\n\t"
+#define EX "v_exp_f32 %7, %7\n\t"
+#define F2 FMB0 FMB1
+          if constexpr (SIDE == S_P_WAIT_IN) T12P("", WT, "", "", "", "", "", "", "", "", "", "");
+          if constexpr (SIDE == S_P_2LD_SAME) T12P(BL0, BL1, "", "", "", "", "", "", "", "", "", "");
+          if constexpr (SIDE == S_P_LD_LAST) T12P("", "", BL0, "", "", "", "", "", BL1, "", "", "");
+          if constexpr (SIDE == S_P_DSR_IN) T12P("", DR, "", "", "", "", "", "", "", "", "", "");
+          if constexpr (SIDE == S_P_DSW_IN) T12P(DW, "", "", DW, "", "", DW, "", "", DW, "", "");
+          if constexpr (SIDE == S_P_DSW_EDGE) T12P("", "", DW, "", "", DW, "", "", DW, "", "", DW);
+          if constexpr (SIDE == S_P_FMA_IN) T12P(F2 FMB0, F2 FMB0, "", F2 FMB0, F2 FMB0, "", F2 FMB0, F2 FMB0, "", F2 FMB0, F2 FMB0, "");
+          if constexpr (SIDE == S_P_ACC_IN) T12P(AR, AR, "", AR, AR, "", AR, AR, "", AR, AR, "");
+          if constexpr (SIDE == S_P_ST_IN) T12P("", ST, "", "", "", "", "", "", "", "", "", "");
+          if constexpr (SIDE == S_P_EXP_IN) T12P(EX FMB0, "", "", EX FMB0, "", "", EX FMB0, "", "", EX FMB0, "", "");
+          if constexpr (SIDE == S_P_EXP_EDGE) T12P("", "", EX FMB0, "", "", EX FMB0, "", "", EX FMB0, "", "", EX FMB0);
+          // a whole weight entry of the Bi-LSTM kernel: two loads, one counted wait, twelve products, a gate piece per tick
+          if constexpr (SIDE == S_P_ENTRY_OLD)
+            asm volatile(BL0 BL1 WT MFB("%0") F2 MFB("%0") F2 MFB("%0") F2 MFB("%1") F2 MFB("%1") F2 MFB("%1") F2 MFB("%2") F2 MFB("%2") F2 MFB("%2") F2 MFB("%3") F2 MFB("%3") F2 MFB("%3") F2
+               : "+a"(acc[(m / 12 * 4) % NACC]), "+a"(acc[(m / 12 * 4 + 1) % NACC]), "+a"(acc[(m / 12 * 4 + 2) % NACC]),
+                 "+a"(acc[(m / 12 * 4 + 3) % NACC]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+s"(sc),
+                 "+v"(ld[0]), "+v"(ld[1]), "+v"(ld2)
+               : "v"(a[(m / 12) & 3]), "v"(b[(m / 4) & 3]), "v"(v1), "v"(gp), "v"(ldsa), "v"(hv), "v"(boff), "s"(rsrc), "s"(goff)
+               : "memory");
+          if constexpr (SIDE == S_P_ENTRY_NEW) T12P(BL0 F2, F2, F2, BL1 F2, F2, F2, F2, F2, F2, F2, WT F2, F2);
+          if constexpr (SIDE == S_P_ENTRY_NEW2) T12P(BL0, F2 F2, F2, BL1, F2 F2, F2, F2, F2, F2, WT, F2 F2, F2);
+          if constexpr (SIDE == S_P_ENTRY_NEW3) T12P(BL0, F2, F2 F2, BL1, F2, F2 F2, F2, F2, F2, WT, F2, F2 F2);
           if constexpr (SIDE == S_ADSW64_NOW) T12M("", "ds_write_b64 %16, %11\n\t");
           if constexpr (SIDE >= S_ALOAD) {
             goff = goff + 2048 < 160 * 1024 ? goff + 2048 : 0;
@@ -228,11 +266,25 @@ int main() {
   RUN("asm: 4 ds_write_b16 per 12 MFMAs", S_ADSW16_4, 3);
   RUN("asm: s_waitcnt vmcnt(14) alone per 12", S_WAITONLY, 3);
   RUN("asm: 2 buffer_load per 12, NO waitcnt", S_ABUF_NOWAIT, 3);
-  RUN("asm: 4 buffer_load per 12, NO waitcnt", S_ABUF8, 3);
   RUN("asm: 1 ds_read_b128 per 12, NO waitcnt", S_ADSR_NOWAIT, 3);
   RUN("asm: 2 buffer_load per 12 at chain edges 0 / 6", S_ABUF_SPREAD, 3);
   RUN("asm: 2 buffer_load per 12 inside chains 1 / 7", S_ABUF_MID, 3);
   RUN("asm: 1 ds_write_b64 per MFMA", S_ADSW64_NOW, 3);
+  RUN("place: s_waitcnt inside a chain", S_P_WAIT_IN, 3);
+  RUN("place: 2 loads inside the SAME chain (0, 1)", S_P_2LD_SAME, 3);
+  RUN("place: 2 loads behind chain ends (2, 8)", S_P_LD_LAST, 3);
+  RUN("place: 1 ds_read_b128 inside a chain", S_P_DSR_IN, 3);
+  RUN("place: 4 ds_write_b16 inside chains (0,3,6,9)", S_P_DSW_IN, 3);
+  RUN("place: 4 ds_write_b16 at chain ends (2,5,8,11)", S_P_DSW_EDGE, 3);
+  RUN("place: 3 v_fma inside chains only (24 per 12)", S_P_FMA_IN, 3);
+  RUN("place: 8 v_accvgpr_read inside chains", S_P_ACC_IN, 3);
+  RUN("place: 1 store inside a chain", S_P_ST_IN, 3);
+  RUN("place: 4 (v_exp + v_fma) inside chains (0,3,6,9)", S_P_EXP_IN, 3);
+  RUN("place: 4 (v_exp + v_fma) at chain ends", S_P_EXP_EDGE, 3);
+  RUN("entry, r03 form: 2 loads + wait in front, 2 v_fma per tick", S_P_ENTRY_OLD, 3);
+  RUN("entry, loads at 0 / 3, wait at 10, 2 v_fma per tick", S_P_ENTRY_NEW, 3);
+  RUN("entry, loads / wait alone in their tick, v_fma moved on", S_P_ENTRY_NEW2, 3);
+  RUN("entry, the same with the v_fma moved to the chain end", S_P_ENTRY_NEW3, 3);
   RUN("chains of 3 + cvt f16 + ds_write_b16", S_DSW, 3);
   RUN("chains of 3 + v_cvt_f16 + v_fma_mix", S_CVT, 3);
   RUN("chains of 3 + ds_read_b128 every 2nd", S_DSR, 3);
