@@ -559,6 +559,7 @@ struct nrv_handle {
     hipEvent_t done = nullptr;
   } lanes[kMaxLanes];
   int n_lanes = 0, lane_rows = 0, lanes_on = 1;
+  int coalesce = 1;                // launch groups below kCoalesce windows are merged (NRV_COALESCE=0: run them as they are, on the lanes)
   hipEvent_t ev_fork = nullptr;
   // staging for the host-pointer entry points
   // two staging sets [set][..]: the upload of group g+1 (copy stream) overlaps the kernels of group g
@@ -873,8 +874,19 @@ static void free_workspace(nrv_handle* h) {
   h->cap_rows = 0;
 }
 
-// Lanes the current batch asks for: 4096 / batch (2 .. kMaxLanes) when a group is <= 2048 windows.
+// Windows per LAUNCH group.  Results do not depend on how the windows of a call are grouped (every window is its own
+// row of every kernel; tests/test_gpu_parity.py pins it bit for bit), and a launch group below 4096 windows leaves most
+// of the chip idle - 512 windows are 32 workgroups of a Bi-LSTM launch on 256 CUs - while every launch pays its fixed
+// cost (staging of weights into LDS, launch boundaries: ~10 % of a 4096-window group's time, all of a 512-window
+// group's).  So consecutive small groups of ONE call are coalesced into launches of kCoalesce windows; `batch` stays
+// what the caller set (nrv_get_batch) and keeps bounding the group from above when it is larger.  r04, config C2
+// (batch 512, E. coli weights): 8.6 M bases/s on eight stream lanes -> the rate of 4096-window groups.
+constexpr int kCoalesce = 4096;
+static int group_windows(const nrv_handle* h) { return (h->coalesce && h->batch < kCoalesce) ? kCoalesce : h->batch; }
+
+// Lanes the current batch asks for (only with NRV_COALESCE=0): 4096 / batch (2 .. kMaxLanes) when a group is <= 2048 windows.
 static int lanes_wanted(const nrv_handle* h) {
+  if (h->coalesce) return 0;
   if (!h->lanes_on || h->batch > 2048 || h->batch % 32) return 0;      // whole row tiles only
   const int w = 4096 / h->batch;
   return w > nrv_handle::kMaxLanes ? nrv_handle::kMaxLanes : w;
@@ -893,7 +905,7 @@ static int read_stage_groups(const nrv_handle* h) {
 static int stage_windows(const nrv_handle* h, bool read_mode = false) {
   const int w = lanes_wanted(h);
   if (w > 1) return w * h->batch;
-  return read_mode ? read_stage_groups(h) * h->batch : h->batch;
+  return read_mode ? read_stage_groups(h) * group_windows(h) : group_windows(h);
 }
 
 static int ensure_workspace(nrv_handle* h) {
@@ -902,7 +914,7 @@ static int ensure_workspace(nrv_handle* h) {
   if (rows <= h->cap_rows) return NRV_OK;
   free_workspace(h);
   // activations: ONE launch group (a stage's groups run one after the other on these, or on the lanes' own sets)
-  const size_t tiles = (size_t)(((h->batch + kRowPad - 1) / kRowPad) * kRowPad) / 32;
+  const size_t tiles = (size_t)(((group_windows(h) + kRowPad - 1) / kRowPad) * kRowPad) / 32;
   // event-major S needs (rows + T + 32) events; window-major S needs rows*T "events"
   for (int m = 0; m < 2; ++m) {
     size_t nS = (tiles * T + 2) * 16 * 128, n1 = tiles * T * 8 * 128, n2 = tiles * T * 32 * 128,
@@ -1481,6 +1493,7 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
          hipEventCreateWithFlags(&h->ev_out[st], hipEventDisableTiming) == hipSuccess;
   if (const char* e2 = getenv("NRV_HOST_REGISTER")) h->host_register = atoi(e2) != 0;
   if (const char* e3 = getenv("NRV_LANES")) h->lanes_on = atoi(e3) != 0;
+  if (const char* e4 = getenv("NRV_COALESCE")) h->coalesce = atoi(e4) != 0;
   ok = ok && hipMalloc((void**)&h->d_sat, 4 * sizeof(unsigned)) == hipSuccess &&
        hipMemset(h->d_sat, 0, 4 * sizeof(unsigned)) == hipSuccess;
   for (int st = 0; st < 2 && ok; ++st) {
@@ -1574,7 +1587,8 @@ int nrv_sync(nrv_handle* h) {
 // (the caller's inputs) and the handle's stream ends behind every lane.  body(first window, windows).
 template <class F>
 static int for_groups(nrv_handle* h, int64_t n, F&& body) {
-  const int64_t ng = (n + h->batch - 1) / h->batch;
+  const int64_t G = group_windows(h);
+  const int64_t ng = (n + G - 1) / G;
   int nl = (h->n_lanes > 1 && ng > 1 && h->prof == 0) ? h->n_lanes : 0;
   if ((int64_t)nl > ng) nl = (int)ng;
   hipStream_t main = h->stream;
@@ -1590,8 +1604,8 @@ static int for_groups(nrv_handle* h, int64_t n, F&& body) {
   }
   int rc = NRV_OK;
   int64_t g = 0;
-  for (int64_t s = 0; s < n && !rc; s += h->batch, ++g) {
-    const int nb = (int)((n - s < h->batch) ? (n - s) : h->batch);
+  for (int64_t s = 0; s < n && !rc; s += G, ++g) {
+    const int nb = (int)((n - s < G) ? (n - s) : G);
     if (nl) {
       const nrv_handle::Lane& L = h->lanes[g % nl];
       for (int m = 0; m < 2; ++m) { h->S[m] = L.S[m]; h->X1[m] = L.X1[m]; h->X2[m] = L.X2[m]; h->X3[m] = L.X3[m]; h->MO[m] = L.MO[m]; }

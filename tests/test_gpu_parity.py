@@ -360,10 +360,11 @@ def test_full_size_properties_device_api(species_models, sp):
     rv.close()
 
 
-def test_small_groups_run_on_lanes_bit_identical(species_models, monkeypatch):
-    """Launch groups of <= 2048 windows are spread over stream lanes with their own activation buffers
-    (nrv_api.hip for_groups): window and read mode, ragged tail, repeated calls - bit-identical to groups
-    of 4096 on one stream and to the same grouping with NRV_LANES=0."""
+def test_small_groups_coalesced_or_on_lanes_bit_identical(species_models, monkeypatch):
+    """Launch groups below 4096 windows: coalesced into 4096-window launches (the default since r04, nrv_api.hip
+    group_windows), or - NRV_COALESCE=0 - spread over stream lanes with their own activation buffers (for_groups),
+    or - NRV_LANES=0 on top - in order on one stream.  Window and read mode, ragged tail, repeated calls: every
+    form bit-identical to groups of 4096 on one stream; nrv_get_batch keeps reporting what the caller set."""
     import torch
     from nanoreviser_amd.engine import Reviser
     m1, m2 = species_models["ecoli"]
@@ -389,7 +390,14 @@ def test_small_groups_run_on_lanes_bit_identical(species_models, monkeypatch):
     ref_rv = Reviser(m1, m2, batch=4096)
     ref = run(ref_rv)
     ref_rv.close()
-    for batch in (512, 992, 1000, 2048):              # 1000: not whole row tiles, stays on one stream
+    for batch in (512, 1000):                         # coalesced
+        rv = Reviser(m1, m2, batch=batch)
+        assert rv.batch == batch
+        for x, y in zip(ref, run(rv)):
+            assert torch.equal(x, y), batch
+        rv.close()
+    monkeypatch.setenv("NRV_COALESCE", "0")
+    for batch in (512, 992, 1000, 2048):              # lanes; 1000: not whole row tiles, stays on one stream
         rv = Reviser(m1, m2, batch=batch)
         for _ in range(2):
             for x, y in zip(ref, run(rv)):

@@ -89,7 +89,8 @@ def test_whole_windows_in_the_conv1_overflow_band(reads, species_models, amp):
     ref32 = rv.predict_pair(sig, fw)
     rv.close()
     bound = min(_conv1_sample_bound(m1), _conv1_sample_bound(m2))
-    assert reruns == (1 if float(np.abs(sig).max()) > bound else 0)
+    if float(np.abs(sig).max()) > bound:
+        assert reruns == 1                       # (below the bound S itself may still leave the range: |S| <= 99 at 1x)
     if reruns:
         for g, r in zip(got, ref32):
             assert np.array_equal(g, r)
