@@ -132,6 +132,14 @@ class Dist:
         import torch
         return int(v) if self.dist is None else int(self._reduce(v, torch.int64, self.dist.ReduceOp.SUM))
 
+    def gather_obj(self, obj):
+        """Every rank's small Python object, in rank order (gloo all_gather_object; [obj] for one rank)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
             self.dist.destroy_process_group()
@@ -303,6 +311,7 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
 
     n, t = bounded(cores, target_s)
     n1, t1 = bounded(1, target_s / 2)
+    blas = blas_grade_baseline(m1, m2, T, sig, rd, cores, target_s / 2)
     ref = "unavailable on this host"
     try:
         import keras  # noqa: F401
@@ -317,6 +326,7 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
                            "sample": f"{n1} windows, 1 thread, {t1:.1f} s"},
             "affinity": {"mask": _mask_str(aff), "n": len(aff), "os_cpu_count": os.cpu_count(),
                          "cgroup_cpu_quota": quota},
+            "blas_grade": blas,
             "host_stage_us_per_base": host_stage_us_per_base(),
             "reference_keras_tf": ref,
             "note": "kind 'port': the reference's path is Python on keras 2.2.4 / tensorflow 1.12, which cannot be "
@@ -324,17 +334,82 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
                     "says nothing about kernel quality, the roofline fraction does."}
 
 
-def load_traffic(T, batch, precision):
-    """HBM bytes per lstm3 launch from the committed PMC pass (profiles/*.json), else None."""
-    for name in ("r03_pmc_lstm3.json", "r02_pmc_lstm3.json", "r01_pmc_lstm3.json"):
+# The Bi-LSTM kernel of each mode as rocprofv3 names it, and the sources it is built from: `roofline.traffic` comes
+# from a COMMITTED PMC pass (profiles/*_pmc_lstm3.json), so it is only printed while that pass still describes the
+# kernel this library runs - same kernel name, same source text (sha256) - and is null, with the reason, otherwise.
+KERNEL_SIGNATURE = {"f16x2": "lstm_h2s_kernel<32, 16, 128, 2, 1, 2, 0, 8, 2, 1, true>",
+                    "bf16x3": "lstm_split_kernel<32, 16, 128, 2, 1, 0>",
+                    "f32": "lstm_layer_kernel<32, 16, 128, 1, 1, false, 0>"}
+KERNEL_SOURCES = {"f16x2": ["nrv_lstm_f16x2s.h", "nrv_lstm_f16x2.h"], "bf16x3": ["nrv_lstm_bf16x3.h"],
+                  "f32": ["nrv_lstm_f32.h"]}
+
+
+def kernel_source_sha(precision):
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in KERNEL_SOURCES[precision]:
+        with open(os.path.join(ROOT, "nanoreviser_amd", "csrc", f), "rb") as fp:
+            hsh.update(fp.read())
+    return hsh.hexdigest()[:16]
+
+
+def blas_grade_baseline(m1, m2, T, sig, rd, cores, budget_s):
+    """The same graph with every contraction on the host's BLAS (PyTorch-CPU: oneDNN / MKL GEMMs, float32,
+    oracle/torch_cpu.py) - what a Keras-on-TF-MKL stack would roughly deliver (NanoReviser.py:37-38 forces the CPU),
+    next to the scalar C port.  Checked against the fp64 oracle on 64 windows before it is timed."""
+    try:
+        import torch
+        from oracle import torch_cpu as TC, nrv_oracle as O
+        torch.set_num_threads(max(1, cores))
+        a, b = TC.TorchCpuModel(m1.tensors), TC.TorchCpuModel(m2.tensors)
+        q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sig[:64], rd[:64], np.float64)
+        p1, p2, _, _ = TC.predict_pair(a, b, sig[:64], rd[:64])
+        dp = max(float(np.abs(p1 - q1).max()), float(np.abs(p2 - q2).max()))
+        if dp > 1e-4:
+            return {"error": f"torch-CPU evaluation is {dp:.2e} from the fp64 oracle: not timed"}
+        n0 = min(len(rd), 512)
+        t0 = time.perf_counter()
+        TC.predict_pair(a, b, sig[:n0], rd[:n0])
+        t_cal = time.perf_counter() - t0
+        n = int(min(len(rd), max(n0, n0 * budget_s / max(t_cal, 1e-3))))
+        reps = max(1, int(budget_s / max(t_cal * n / n0, 1e-3))) if n == len(rd) else 1
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            TC.predict_pair(a, b, sig[:n], rd[:n])
+        t = time.perf_counter() - t0
+        return {"value": n * reps / t, "unit": "bases/s", "cores": cores, "kind": "port (BLAS-grade)",
+                "dtype": "f32", "max_abs_dp_vs_fp64_oracle_64_windows": dp,
+                "sample": f"{n} windows x {reps}, model1+model2, torch {torch.__version__} CPU with {cores} threads, {t:.1f} s",
+                "note": "oneDNN / MKL GEMMs for the convolutions, dense layers and the Bi-LSTM input projections (all T "
+                        "steps per GEMM), one GEMM per recurrent step; reported baseline only"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def load_traffic(T, batch, precision, profiles_dir=None):
+    """(HBM bytes per lstm3 launch, source description) from the newest committed PMC pass that still matches the
+    kernel; (None, why) when there is none."""
+    import glob
+    why = "no committed PMC pass for this mode / shape"
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_pmc_lstm3.json")), reverse=True):
         try:
-            j = json.load(open(os.path.join(ROOT, "profiles", name)))
-            j = j.get(precision)
-            if j and j.get("T") == T and j.get("batch") == batch:
-                return j.get("hbm_bytes_per_launch")
+            j = json.load(open(path)).get(precision)
         except Exception:
-            pass
-    return None
+            continue
+        if not j or j.get("T") != T or j.get("batch") != batch:
+            continue
+        name = os.path.relpath(path, ROOT) if profiles_dir is None else os.path.basename(path)
+        if "kernel_name" in j and KERNEL_SIGNATURE[precision] not in j["kernel_name"]:
+            why = f"{name} describes another kernel ({j['kernel_name'][:60]}...): not printed"
+            continue
+        if "source_sha256_16" in j and j["source_sha256_16"] != kernel_source_sha(precision):
+            why = f"{name} was collected on another version of {' + '.join(KERNEL_SOURCES[precision])}: stale, not printed"
+            continue
+        if "kernel_name" not in j or "source_sha256_16" not in j:
+            why = f"{name} carries no kernel name / source hash (rounds 1-3): not trusted for the current kernel"
+            continue
+        return j.get("hbm_bytes_per_launch"), f"{name} @ {j.get('commit', '?')}: {j.get('source', '')}"
+    return None, why
 
 
 # ------------------------------------------------------------------------------------------------
@@ -551,7 +626,7 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
     out["roofline" + suffix] = {
         "kernel": f"{KERNEL_NAME[precision]} ({k3})", "bound": "mfma", "achieved": ach, "peak": peak,
         "unit": "TFLOP/s", "frac": ach / peak,
-        "traffic": load_traffic(T, B, precision),
+        "traffic": load_traffic(T, B, precision)[0], "traffic_source": load_traffic(T, B, precision)[1],
         "flop_per_launch": fl, "avg_launch_us": avg_s * 1e6, "launches": n_l,
         "avg_launch_us_bracketed": raw_s * 1e6, "empty_bracket_us": m.get("bracket_overhead_us", 0.0),
         "avg_launch_us_untimed_pass": kernel_us.get(k3),
@@ -666,13 +741,15 @@ def run_dry(args):
     eng = DryRunEngine(hi - lo, args.window, 20260 + d.rank)
     elapsed, _ = timed_steps(d, eng.step, lambda: None, args.steps, args.warmup)
     total = d.sum_int((hi - lo) * args.steps)
+    ranks = d.gather_obj({"rank": d.rank, "pid": os.getpid(), "shard": [lo, hi]})     # the real run gathers device identities this way
     if d.rank == 0:
         print(json.dumps({
             "metric": "bases revised/sec (whole node)", "value": total / elapsed, "unit": "bases/s",
             "n_gpus": args.gpus, "world_size": d.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "none", "data": "dry-run (CPU control path only; no engine, rate is meaningless)",
-            "config": {"workload": "dry run", "batch_windows_per_gpu": args.batch, "window": args.window}}), flush=True)
+            "config": {"workload": "dry run", "batch_windows_per_gpu": args.batch, "window": args.window,
+                       "world_size": d.world, "ranks": ranks}}), flush=True)
     d.close()
     return 0
 
@@ -703,6 +780,13 @@ def run_rank(args):
         device = local_rank
     torch.cuda.set_device(device)
     d = Dist()
+    # which physical device this rank drives: index, PCI bus id, UUID.  The data path has no collective, so "N ranks
+    # seen" cannot be read off RCCL: config.devices is the proof that an N-GPU line ran on N DISTINCT devices.
+    pr = torch.cuda.get_device_properties(device)
+    ident = {"rank": d.rank, "local_rank": local_rank, "device": device, "name": pr.name,
+             "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+             "uuid": str(getattr(pr, "uuid", ""))}
+    devices = d.gather_obj(ident)
 
     T, B = args.window, args.batch
     m1, m2 = load_species(args.species)
@@ -761,6 +845,8 @@ def run_rank(args):
             "precision": args.precision,
             "parallelism": f"read/window-sharded x{args.gpus}, no collectives; control plane on gloo (CPU tensors)"
                            + (f"; --share-device: {d.world} ranks on {ndev} device(s)" if args.share_device else ""),
+            "world_size": d.world, "devices": devices,
+            "distinct_devices": len({(x["pci"], x["uuid"]) for x in devices}),
             "parity_guard_max_abs_dp": dp,
             "prime_note": f"{args.prime} untimed priming steps, then untimed blocks of 200 steps until three in a row agree "
                           f"within 1 % (<= 40 blocks), precede the {args.warmup} warm-up steps (clock settling)",
@@ -776,6 +862,11 @@ def run_rank(args):
         del d_sig, d_rd
         try:
             out.update(extras(args, torch, dev, device, m1, m2, sig, rd, ms_per_step, cli_helper))
+            # the reference-precision figure next to `value` (same protocol, same run): nobody should have to dig for it
+            if "roofline_f32" in out:
+                out["value_f32"] = out["roofline_f32"]["bases_per_s"]
+                out["ms_per_step_f32"] = out["roofline_f32"]["ms_per_step"]
+                out["dtype_f32"] = DTYPE["f32"]
         except Exception as e:                               # never lose the main line to a secondary block
             out["extras_error"] = repr(e)
     if cli_helper is not None:

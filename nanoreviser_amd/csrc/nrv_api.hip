@@ -159,7 +159,8 @@ NRV_HOST_COLD static void pack_lstm_split(const Blob& b, int base, int Kin, int 
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
-// ---- f16x2 packing (lstm_h2o_kernel, nrv_lstm_f16x2.h) -----------------------------------------------
+
+// ---- f16x2 packing (nrv_lstm_f16x2.h) -----------------------------------------------
 // largest s with bound * 2^s <= 2^14 (f16 overflows at 65504: two binades of head-room)
 static int pow2_room(float bound) {
   if (!(bound > 0.f)) return 14;
@@ -193,48 +194,6 @@ static inline void split_f16(float v, uint16_t* hi, uint16_t* lo) {
   memcpy(hi, &h, 2);
   memcpy(lo, &l, 2);
 }
-// [dir][hg][kb][gate][term 2][64 lanes][8 f16]; lane l holds k = 16*kb + 8*(l>>5) + j, column (gate,
-// unit hg*32 + (l&31)); input rows k < K0 are scaled by 2^(E - s0), k >= K0 by 2^(E - s1), recurrent
-// rows by 2^(E - 13).  bias [dir][hg][gate][32] x 2^E.
-// gpt = gates per 32-column tile (lstm_h2o_kernel's GPT): a wave's group holds upw = 32 / gpt hidden units and
-// 4 / gpt tiles per k-block; column n of tile tl is gate tl gpt + n / upw of unit n % upw.
-NRV_HOST_COLD static void pack_lstm_h2(const Blob& b, int base, int K0, int s0, int K1, int s1, int H, int E,
-                                       std::vector<float>& out, std::vector<float>& bias, int gpt = 1) {
-  const int Kin = K0 + K1;
-  const int upw = 32 / gpt, ngt = 4 / gpt;
-  const int NG = (H + upw - 1) / upw, KB_IN = Kin / 16, KB = KB_IN + H / 16;
-  std::vector<uint16_t> w((size_t)2 * NG * KB * ngt * 2 * 64 * 8, 0);
-  bias.assign((size_t)2 * NG * 4 * upw, 0.f);
-  NRV_FOR (int dir = 0; dir < 2; ++dir) {
-    const float* W = b.t(base + dir * 3 + 0);
-    const float* U = b.t(base + dir * 3 + 1);
-    const float* B = b.t(base + dir * 3 + 2);
-    NRV_FOR (int hg = 0; hg < NG; ++hg) {
-      NRV_FOR (int kb = 0; kb < KB; ++kb)
-        NRV_FOR (int tl = 0; tl < ngt; ++tl)
-          NRV_FOR (int lane = 0; lane < 64; ++lane)
-            NRV_FOR (int j = 0; j < 8; ++j) {
-              const int n = lane & 31, g = tl * gpt + n / upw, unit = hg * upw + n % upw;
-              float v = 0.f;
-              if (unit < H) {
-                const int k = 16 * (kb < KB_IN ? kb : kb - KB_IN) + 8 * (lane >> 5) + j;
-                if (kb < KB_IN) v = std::ldexp(W[(size_t)k * 4 * H + g * H + unit], E - (k < K0 ? s0 : s1));
-                else v = std::ldexp(U[(size_t)k * 4 * H + g * H + unit], E - 13);
-              }
-              const size_t o = (((((size_t)(dir * NG + hg) * KB + kb) * ngt + tl) * 2) * 64 + lane) * 8 + j;
-              split_f16(v, &w[o], &w[o + 64 * 8]);
-            }
-      NRV_FOR (int g = 0; g < 4; ++g)
-        NRV_FOR (int c = 0; c < upw; ++c) {
-          const int unit = hg * upw + c;
-          bias[((size_t)(dir * NG + hg) * 4 + g) * upw + c] = unit < H ? std::ldexp(B[g * H + unit], E) : 0.f;
-        }
-    }
-  }
-  out.assign((w.size() + 1) / 2, 0.f);
-  memcpy(out.data(), w.data(), w.size() * 2);
-}
-
 // lstm_h2s_kernel (16x16x32 tiles): [dir][wave group of 16 uh units][kk 32-k blocks: input, then recurrent]
 // [gate][unit half][term][64 lanes][8 f16]; lane l: k = 32 kk + 8 (l >> 4) + j, unit = 16 (wg uh + h) + (l & 15).
 NRV_HOST_COLD static void pack_lstm_h2s(const Blob& b, int base, int K0, int s0, int K1, int s1, int H, int E,
@@ -423,23 +382,6 @@ NRV_HOST_COLD static HeadH2Scales pack_head_h2(const Blob& b, std::vector<float>
   return HeadH2Scales{std::ldexp(1.f, s1 - E1), std::ldexp(1.f, s2 - E2), std::ldexp(1.f, -E3)};
 }
 
-// cnn_h2_kernel: dense 400->64 x 2^wexp as f16x2 B fragments of v_mfma_f32_16x16x32_f16:
-// [ks 13][ct 4][term 2][64 lanes][8 f16]; lane l, element j hold W[k][n] with k = 32*ks + 8*(l>>4) + j
-// (flatten index p*8+o; rows >= 400 are zero), n = 16*ct + (l&15).
-NRV_HOST_COLD static void pack_cnn_h2(const float* W, int wexp, std::vector<float>& out) {
-  std::vector<uint16_t> w((size_t)13 * 4 * 2 * 512, 0);
-  NRV_FOR (int ks = 0; ks < 13; ++ks)
-    NRV_FOR (int ct = 0; ct < 4; ++ct)
-      NRV_FOR (int lane = 0; lane < 64; ++lane)
-        NRV_FOR (int j = 0; j < 8; ++j) {
-          const int k = 32 * ks + 8 * (lane >> 4) + j;
-          const float v = k < 400 ? std::ldexp(W[(size_t)k * 64 + 16 * ct + (lane & 15)], wexp) : 0.f;
-          const size_t o = ((size_t)((ks * 4 + ct) * 2) * 64 + lane) * 8 + j;
-          split_f16(v, &w[o], &w[o + 512]);
-        }
-  out.assign(w.size() / 2, 0.f);
-  memcpy(out.data(), w.data(), w.size() * 2);
-}
 
 // lstm1 (6 -> 16) for the 16x16x4 kernel.  Per direction [6][gate 4][64 lanes]:
 //   input k-step s (0,1):   W[k = 4s + (lane>>4)][g*16 + (lane&15)]       (k >= 6 -> 0)
@@ -518,11 +460,7 @@ struct DevModel {
   size_t h_ws, h_wb;          // head_mlp_split_kernel: split weights / biases
   // f16x2 mode (nrv_lstm_f16x2.h): lstm2..4 weights as two f16 terms, scaled biases, output scale /
   // shift with the buffer exponents folded in, the producers' scaled epilogue constants
-  size_t l_w2[4], l_b2[4], l_s2[4], l_h2[4];
-#ifdef NRV_EXPERIMENTS
-  size_t l_w2g[4], l_b2g[4];        // the same packed two gates per tile (lstm_h2o_kernel GPT = 2)
-#endif
-  size_t l_w2s[4], l_b2s[4];        // packed for lstm_h2s_kernel (16x16x32 tiles; unit halves per wave: kUhS)
+  size_t l_s2[4], l_h2[4];
   // layers 2, 3 (192->128, 256->64) with the BatchNorm IN FRONT of them folded into their weights and bias:
   // their BatchNorm'd input segment is then the raw h x 2^13 of the layer before (lstm2_t / lstm_h2s RAW copy-out)
   size_t l_w2sf[4] = {0, 0, 0, 0}, l_b2sf[4] = {0, 0, 0, 0};
@@ -530,8 +468,7 @@ struct DevModel {
   size_t l2t_w = 0, l2t_b = 0;      // lstm2_t_kernel: transposed fragments / bias image of the 32->64 layer
   float descale[4];
   size_t l1s2, l1h2;
-  size_t conv_h2, dsplit_h2, dbias_h2;   // cnn_h2_kernel: conv constants with bn2 x 2^6, dense x 2^10 (f16x2), bias x 2^16
-  size_t cm_w2 = 0, cm_ep = 0;           // cnn_m_kernel: second convolution as an A operand, its epilogue constants
+  size_t cr_dbias = 0;                   // cnn_r_kernel: dense bias x 2^16
   size_t cr_w2 = 0, cr_ep = 0, cr_d = 0; // cnn_r_kernel: conv2 in its two-position form, epilogue constants, dense A fragments
   CnnRConsts cr_k;                       // ... and the first convolution's constants (kernel arguments)
   size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
@@ -589,9 +526,6 @@ struct nrv_handle {
                                    // as f16 split planes (cnn dense and head stay on their bf16x3 kernels)
   int split = 62;                  // bit l set: layer l (1..3 = lstm2..4, 4 = head dense layers, 5 = signal-branch
                                    // dense) runs its split-bf16 kernel (nrv_set_precision: BF16X3 = 62, F32 = 0)
-#ifdef NRV_EXPERIMENTS
-  int geo[4] = {-1, 2, 0, 2};       // index into kGeo for lstm1..4 (NRV_GEO)
-#endif
   std::string err;
   // profiling
   int prof = 0;                      // 0 off, 1 every kernel, 2 only slot 3 (lstm3, the dominant kernel),
@@ -683,37 +617,23 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     d.l1s2 = put_scaled(sc1, sX1);                       // lstm1 keeps h unscaled in its LDS image
     d.l1h2 = put_scaled(sh1, sX1);
     {
-      // cnn_h2_kernel: the conv features live in LDS as x 2^6 f16 pairs, the dense weights as x 2^10
-      static_assert(sS == 6, "kImgScale / kDenseDescale in nrv_cnn_f16x2.h assume S x 2^6");
+      // cnn_r_kernel (nrv_cnn_r.h): c1 and the conv features travel x 2^6 as f16 pairs, the dense weights x 2^10
+      static_assert(sS == 6, "kCnnRImgScale / kCnnRDenseDescale in nrv_cnn_r.h assume S x 2^6");
       float cv[264];
       memcpy(cv, host.data() + d.conv, 264 * 4);
       NRV_FOR (int o = 0; o < 8; ++o) { cv[248 + o] = std::ldexp(cv[248 + o], 6); cv[256 + o] = std::ldexp(cv[256 + o], 6); }
-      d.conv_h2 = put(cv, 264);
-      pack_cnn_h2(b.t(32), 10, wp);
-      d.dsplit_h2 = put(wp.data(), wp.size());
+      // the second convolution x 2^u is the A operand of a transposed product; c1 is kept x 2^6, so its accumulator
+      // holds z x 2^(6+u)
       std::vector<float> db(b.t(33), b.t(33) + 64);
-      d.dbias_h2 = put_scaled(db, 16);
-      // cnn_m_kernel (nrv_cnn_m.h): the second convolution x 2^u as the A operand of the transposed product,
-      // [term][lane (co = l & 15, tap = l >> 4)][ci]; c1 is kept x 2^6, so the accumulator holds z x 2^(6+u)
+      d.cr_dbias = put_scaled(db, 16);                         // dense bias x 2^16
       const float* w2 = host.data() + d.conv + 48;             // [tap][ci][co]
       const int u = pow2_room(max_abs(w2, 192));
-      std::vector<uint16_t> frag((size_t)2 * 64 * 8, 0);
-      NRV_FOR (int lane = 0; lane < 64; ++lane)
-        NRV_FOR (int j = 0; j < 8; ++j) {
-          const int co = lane & 15, tap = lane >> 4;
-          const float v = (co < 8 && tap < 3) ? std::ldexp(w2[(tap * 8 + j) * 8 + co], u) : 0.f;
-          split_f16(v, &frag[(size_t)lane * 8 + j], &frag[(size_t)512 + lane * 8 + j]);
-        }
-      std::vector<float> ff(frag.size() / 2);
-      memcpy(ff.data(), frag.data(), frag.size() * 2);
-      d.cm_w2 = put(ff.data(), ff.size());
       float ep[48] = {0};
       NRV_FOR (int co = 0; co < 8; ++co) {
         ep[co] = std::ldexp(cv[240 + co], 6 + u);              // bias of the second convolution
         ep[16 + co] = std::ldexp(cv[248 + co], -6 - u);        // cv[248..]: BatchNorm 2 scale, already x 2^6 -> s2 x 2^-u
         ep[32 + co] = cv[256 + co];                            // BatchNorm 2 shift x 2^6
       }
-      d.cm_ep = put(ep, 48);
       {
         // cnn_r_kernel (nrv_cnn_r.h).  conv2's A operand gives TWO positions per product: rows 0-7 take tap = k-group,
         // rows 8-15 tap = k-group - 1 (the B operand's k-groups hold c1 at positions p - 1 .. p + 2).
@@ -777,17 +697,6 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
     d.h_b2 = put(bs.data(), bs.size());
     NRV_FOR (int l = 1; l < 4; ++l) {
       const int E = plan_exponent(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l]);
-      pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs);
-      d.l_w2[l] = put(wp.data(), wp.size());
-      d.l_b2[l] = put(bs.data(), bs.size());
-#ifdef NRV_EXPERIMENTS
-      pack_lstm_h2(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, 2);
-      d.l_w2g[l] = put(wp.data(), wp.size());
-      d.l_b2g[l] = put(bs.data(), bs.size());
-#endif
-      pack_lstm_h2s(b, lbase[l], K0[l], s0[l], K1[l], s1[l], lH[l], E, wp, bs, kUhS[l]);
-      d.l_w2s[l] = put(wp.data(), wp.size());
-      d.l_b2s[l] = put(bs.data(), bs.size());
       if (l == 1) {
         pack_lstm2_t(b, lbase[1], sX1, E, wp, bs);
         d.l2t_w = put(wp.data(), wp.size());
@@ -1004,35 +913,6 @@ static void launch_lstm_f32(nrv_handle* h, const LstmArgs& a, int tiles) {
 #endif
 }
 
-#ifdef NRV_EXPERIMENTS
-struct Geo { int R, WR; };
-static const Geo kGeo[5] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}, {2, 2}};
-
-template <int KQ0, int KQ1, int H, bool PLAIN>
-static void launch_lstm(nrv_handle* h, const LstmArgs& a, int tiles, int geo) {
-  constexpr int NG = (H + 31) / 32;
-  // at most 4 waves per workgroup (one per SIMD, 512 registers each): WR is clamped to 4/NG
-#define NRV_L(RR, WREQ, ACT)                                                                   \
-  {                                                                                            \
-    constexpr int WW = (NG * WREQ > 4) ? (4 / NG) : WREQ;                                      \
-    LstmArgs la = a;                                                                           \
-    la.n_blk = (tiles + RR * WW - 1) / (RR * WW);                                              \
-    hipLaunchKernelGGL((lstm_layer_kernel<KQ0, KQ1, H, RR, WW, PLAIN, ACT>),                  \
-                       dim3(lstm_grid(la.n_blk)), dim3(64 * NG * WW), 0, h->stream, la);       \
-  }
-#define NRV_G(ACT)                                                                             \
-  switch (geo) {                                                                               \
-    case 1: NRV_L(2, 1, ACT); break;                                                           \
-    case 2: NRV_L(1, 2, ACT); break;                                                           \
-    case 3: NRV_L(1, 4, ACT); break;                                                           \
-    case 4: NRV_L(2, 2, ACT); break;                                                           \
-    default: NRV_L(1, 1, ACT); break;                                                          \
-  }
-  if (h->act == 0) { NRV_G(0) } else { NRV_G(1) }
-#undef NRV_G
-#undef NRV_L
-}
-#endif
 
 template <int KQ0, int KQ1, int H, int R, int WR>
 static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* const ws[2], int tiles) {
@@ -1052,19 +932,13 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
   // measured 335 -> 362 us even with the cell state moved to LDS: the remaining spill reloads drain
   // the in-order prefetch queue), so that layer keeps lstm_split_kernel.
   if constexpr (R == 1) {
-#ifdef NRV_EXPERIMENTS
-    static const bool pair_ok = !(getenv("NRV_PAIR") && atoi(getenv("NRV_PAIR")) == 0);   // NRV_PAIR=0: pairs off
-    if (pair_ok)
-#endif
     {
       if (h->act == 0) hipLaunchKernelGGL((lstm_pair_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);
       NRV_ACT1(else hipLaunchKernelGGL((lstm_pair_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);)
       return;
     }
   }
-#ifndef NRV_EXPERIMENTS
   if constexpr (R != 1)
-#endif
   {
     if (h->act == 0) hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 0>), grid, blk, 0, h->stream, sa);
     NRV_ACT1(else hipLaunchKernelGGL((lstm_split_kernel<KQ0, KQ1, H, R, WR, 1>), grid, blk, 0, h->stream, sa);)
@@ -1072,41 +946,18 @@ static void launch_lstm_split(nrv_handle* h, const LstmArgs& a, const float* con
 #endif
 }
 
-template <int KQ0, int KQ1, int H, int R, int WR, bool OUT_F32, int NBG, int NA, int GPT = 1, int KBL = 0>
-static void launch_lstm_h2(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
-                           float* const out[2], int T, int n, int tiles) {
-  constexpr int NG = (H * GPT + 31) / 32;
-  LstmH2Args sa;
-  sa.T = T; sa.n_rows = n;
-  for (int m = 0; m < 2; ++m) {
-    const DevModel& d = h->dm[m];
-#ifdef NRV_EXPERIMENTS
-    const size_t ow = GPT == 2 ? d.l_w2g[layer] : d.l_w2[layer], ob = GPT == 2 ? d.l_b2g[layer] : d.l_b2[layer];
-#else
-    static_assert(GPT == 1, "two gates per tile: experiments build only");
-    const size_t ow = d.l_w2[layer], ob = d.l_b2[layer];
-#endif
-    sa.m[m] = LstmH2ModelParams{d.all + ow, d.all + ob, d.all + d.l_s2[layer], d.all + d.l_h2[layer], in0[m], in1[m],
-                                out[m], d.descale[layer]};
-  }
-  sa.n_blk = (tiles + R * WR - 1) / (R * WR);
-  dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 0, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);
-  NRV_ACT1(else hipLaunchKernelGGL((lstm_h2o_kernel<KQ0, KQ1, H, R, WR, 1, OUT_F32, NBG, NA, GPT, KBL>), grid, blk, 0, h->stream, sa);)
-}
-
 template <int KQ0, int KQ1, int H, int R, int WR, int UH, int NBG, int NA, int KBL = 0, bool RAW = false>
 static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
-                            float* const out[2], int T, int n, int tiles, bool folded_in = false) {
+                            float* const out[2], int T, int n, int tiles) {
   constexpr int NG = H / (16 * UH);
   LstmH2Args sa;
   sa.T = T; sa.n_rows = n;
   for (int m = 0; m < 2; ++m) {
     const DevModel& d = h->dm[m];
-    sa.m[m] = LstmH2ModelParams{d.all + (folded_in ? d.l_w2sf[layer] : d.l_w2s[layer]),
-                                d.all + (folded_in ? d.l_b2sf[layer] : d.l_b2s[layer]),
+    // weights with the BatchNorm in FRONT of the layer folded in (upload_model)
+    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2sf[layer], d.all + d.l_b2sf[layer],
                                 d.all + d.l_s2[layer], d.all + d.l_h2[layer], in0[m], in1[m], out[m],
-                                folded_in ? d.descale_f[layer] : d.descale[layer]};
+                                d.descale_f[layer]};
   }
   sa.n_blk = (tiles + R * WR - 1) / (R * WR);
   dim3 grid(lstm_grid(sa.n_blk)), blk(64 * NG * WR);
@@ -1151,37 +1002,11 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
     const int n_tiles = read_mode ? (n + T - 1 + 31) / 32 : tiles * T;
     // persistent workgroups, one per CU: 128 per model (blockIdx.y) on the 256 CUs
     const int blocks = n_tiles < 128 ? n_tiles : 128;
-#ifdef NRV_EXPERIMENTS
-    // NRV_CNN=h2: convolutions on the VALU, feature image in LDS (cnn_h2_kernel); m: the 8 -> 8 convolution on the matrix
-    // pipe, feature image in LDS (cnn_m_kernel); default: everything in registers (cnn_r_kernel)
-    static const char* cnnv = getenv("NRV_CNN");
-    const bool cnn_h2v = cnnv && !strcmp(cnnv, "h2"), cnn_mv = cnnv && !strcmp(cnnv, "m");
-    if (h->h2 && cnn_mv) {
-      CnnMArgs a2;
-      for (int m = 0; m < 2; ++m) {
-        const DevModel& d = h->dm[m];
-        a2.m[m] = CnnH2ModelParams{d.all + d.conv_h2, d.all + d.dsplit_h2, d.all + d.dbias_h2, h->S[m]};
-        a2.c[m] = CnnMModelParams{d.all + d.cm_w2, d.all + d.cm_ep};
-        static_assert(sizeof(CnnRConsts) == sizeof(CnnMConsts), "same constants");
-        memcpy(&a2.k[m], &d.cr_k, sizeof(CnnMConsts));
-      }
-      a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
-      hipLaunchKernelGGL(cnn_m_kernel, dim3(blocks, 2), dim3(kCnnH2Threads), 0, h->stream, a2);
-    } else if (h->h2 && cnn_h2v) {
-      CnnH2Args a2;
-      for (int m = 0; m < 2; ++m) {
-        const DevModel& d = h->dm[m];
-        a2.m[m] = CnnH2ModelParams{d.all + d.conv_h2, d.all + d.dsplit_h2, d.all + d.dbias_h2, h->S[m]};
-      }
-      a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
-      hipLaunchKernelGGL(cnn_h2_kernel, dim3(blocks, 2), dim3(kCnnH2Threads), 0, h->stream, a2);
-    } else
-#endif
     if (h->h2) {
       CnnRArgs a2;
       for (int m = 0; m < 2; ++m) {
         const DevModel& d = h->dm[m];
-        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.dbias_h2, h->S[m]};
+        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.cr_dbias, h->S[m]};
         a2.k[m] = d.cr_k;
       }
       a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
@@ -1236,16 +1061,6 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   {
     LstmArgs a;
     a.T = T; a.n_rows = n;
-#ifdef NRV_EXPERIMENTS
-    if (h->geo[0] >= 0 && !h->h2) {
-      for (int m = 0; m < 2; ++m) {
-        const DevModel& d = h->dm[m];
-        a.m[m] = LstmModelParams{d.all + d.l_w[0], d.all + d.l_b[0], d.all + d.l_s[0], d.all + d.l_h[0],
-                                 ActView{}, ActView{}, d_feat, read_mode ? 1 : 0, h->X1[m]};
-      }
-      launch_lstm<0, 0, 16, true>(h, a, tiles, h->geo[0]);
-    } else
-#endif
     if (!h2_fused_l1) {                          // the dedicated 16x16x4 kernel (f32 in every mode)
       Lstm1Args a1;
       a1.T = T; a1.n_rows = n;
@@ -1268,14 +1083,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
     }
     const ActView none[2] = {ActView{}, ActView{}};
-#ifdef NRV_EXPERIMENTS
-    // NRV_L2T=0: the 32->64 layer on lstm_h2o_kernel (hidden units on the lanes, h through LDS, BatchNorm in its epilogue)
-    static const bool l2t = !(getenv("NRV_L2T") && atoi(getenv("NRV_L2T")) == 0);
-#else
-    constexpr bool l2t = true;
-#endif
     if (h2_fused_l2) {}
-    else if (h->h2 && l2t) {
+    else if (h->h2) {
       // wave-private transposed kernel; hands over h x 2^13 (BatchNorm(128) is in the 192->128 layer's weights)
       Lstm2TArgs ta;
       ta.T = T; ta.n_rows = n;
@@ -1287,22 +1096,11 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
       NRV_ACT1(else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);)
     }
-#ifdef NRV_EXPERIMENTS
-    else if (h->h2) {
-      const ActView i0[2] = {win_view(h->X1[0], 8), win_view(h->X1[1], 8)};
-      float* const o[2] = {h->X2[0], h->X2[1]};
-      launch_lstm_h2<8, 0, 64, 1, 2, false, 8, 2>(h, 1, i0, none, o, T, n, tiles);
-    }
-#endif
     else if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
       launch_lstm_split<8, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
-#ifdef NRV_EXPERIMENTS
-      launch_lstm<8, 0, 64, false>(h, a, tiles, h->geo[1]);
-#else
       launch_lstm_f32<8, 0, 64, 1, 2>(h, a, tiles);
-#endif
     }
     if ((rc = mark(3))) return rc;
     for (int m = 0; m < 2; ++m) {
@@ -1319,24 +1117,12 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // both big layers on lstm_h2s_kernel: this one hands over h x 2^13 as it lies in LDS and the BatchNorm
       // behind it lives in the next layer's weights
       // (cell state in registers; 1 of its 10 weight k-blocks of 32 resident in LDS: 64 KB)
-#ifdef NRV_EXPERIMENTS
-      // NRV_MFMA16: bit 0 / bit 1 = the 192->128 / 256->64 layer on the 16x16x32 tile (default 3: both, BatchNorm folded)
-      static const int m16b = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
-      if (m16b != 3) {
-        if (m16b & 1) launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2>(h, 2, i0, i1, o, T, n, tiles, l2t);
-        else launch_lstm_h2<32, 16, 128, 2, 1, false, 8, 4>(h, 2, i0, i1, o, T, n, tiles);      // (needs NRV_L2T=0)
-      } else
-#endif
-      launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles, l2t);
+      launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles);
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
     } else {
-#ifdef NRV_EXPERIMENTS
-      launch_lstm<32, 16, 128, false>(h, a, tiles, h->geo[2]);
-#else
       launch_lstm_f32<32, 16, 128, 1, 1>(h, a, tiles);
-#endif
     }
     if ((rc = mark(4))) return rc;
     for (int m = 0; m < 2; ++m) {
@@ -1349,25 +1135,12 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2; split planes for head_h2_kernel
       // no BatchNorm behind this layer (RAW); the one in front of it is folded into its weights;
       // 3 of its 10 weight k-blocks of 32 stay in LDS (96 KB; -3 %)
-#ifdef NRV_EXPERIMENTS
-      static const int m16 = getenv("NRV_MFMA16") ? atoi(getenv("NRV_MFMA16")) : 3;
-      static const bool ht = !(getenv("NRV_HT") && atoi(getenv("NRV_HT")) == 0);   // NRV_HT=0: one gate per tile
-      if (!(m16 & 2)) {
-        if (ht) launch_lstm_h2<64, 0, 64, 2, 1, false, 8, 4, 2, 7>(h, 3, i0, none, o, T, n, tiles);
-        else launch_lstm_h2<64, 0, 64, 1, 2, false, 16, 4>(h, 3, i0, none, o, T, n, tiles);
-      } else if (m16 != 3) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles, false);
-      else
-#endif
-      launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles, true);
+      launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
     } else {
-#ifdef NRV_EXPERIMENTS
-      launch_lstm<64, 0, 64, false>(h, a, tiles, h->geo[3]);
-#else
       launch_lstm_f32<64, 0, 64, 1, 2>(h, a, tiles);
-#endif
     }
     if ((rc = mark(5))) return rc;
   }
@@ -1471,14 +1244,6 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
     else if (!strcmp(s, "bf16x3")) { h->split = 62; h->h2 = 0; }
     else if (!strcmp(s, "f16x2")) { h->split = 62; h->h2 = 1; }
   }
-#ifdef NRV_EXPERIMENTS
-  if (const char* s = getenv("NRV_SPLIT")) h->split = atoi(s) & 62;   // tuning knob: per-layer mask
-  if (const char* s = getenv("NRV_GEO")) {     // tuning knob: kGeo index per Bi-LSTM layer, e.g. NRV_GEO=2,2,0,2
-    int r[4];
-    if (sscanf(s, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4)
-      for (int i = 0; i < 4; ++i) h->geo[i] = (r[i] >= (i == 0 ? -1 : 0) && r[i] < 5) ? r[i] : 0;
-  }
-#endif
   int rc = NRV_OK;
   // a BLOCKING stream: it orders itself against the legacy default stream, so inputs produced on
   // the default stream (torch's default) are complete before our first kernel reads them

@@ -16,27 +16,28 @@
 //     so that one wave-wide 16-byte load IS an A fragment and is a single contiguous 1 KiB request.
 //     Weights are pre-packed on the host into the matching B-fragment order (f32 and split-bf16
 //     forms), so B operands stream L2 -> VGPR with no LDS staging.
-//   * Six launches per group of windows in the default mode: cnn_h2_kernel (signal branch),
-//     lstm1_kernel, lstm_h2o_kernel (32->64) and two lstm_h2s_kernel (192->128, 256->64: 16x16x32
-//     tiles) Bi-LSTM layers, head_h2_kernel (seven in the other modes:
-//     cnn_kernel, lstm1_kernel, lstm_pair_kernel / lstm_split_kernel or lstm_layer_kernel,
-//     head_mlp(_split)_kernel, head_final_kernel); plus segment_kernel when reads arrive as raw
+//   * FIVE launches per group of 4096 windows in the default (f16x2) mode:
+//       cnn_r_kernel      signal branch (conv1 on the VALU -> conv2 -> dense 400->64 on the matrix pipe, in registers)
+//                         + the 6->16 Bi-LSTM (lstm1_unit) as four more waves of the same workgroups
+//       lstm2_t_kernel    32->64 Bi-LSTM, transposed products, wave-private recurrence
+//       lstm_h2s_kernel   192->128 Bi-LSTM <32,16,128,...> and 256->64 Bi-LSTM <64,0,64,...>, 16x16x32 f16 tiles
+//       head_h2_kernel    per-timestep MLP 128->128->32->6 + flatten, feature dense, softmax, argmax
+//     seven in the bf16x3 / f32 modes (cnn_kernel, lstm1_kernel, lstm_pair_kernel / lstm_split_kernel or
+//     lstm_layer_kernel x3, head_mlp(_split)_kernel, head_final_kernel); plus segment_kernel when reads arrive as raw
 //     samples.  Rows (windows) are independent: no inter-workgroup communication anywhere.
-//   * One Bi-LSTM layer = one launch; a wave owns 32 hidden units x 4 gates x R row tiles, so
-//     i,f,g,o of one (window, unit) sit in the same lane/register and the cell update is
-//     register-local; c never leaves the wave, h_t goes through a double-buffered LDS image
-//     (one barrier per step) and is written out coalesced with the following BatchNorm fused.
+//   * One Bi-LSTM layer = one launch; a wave owns a group of hidden units x 4 gates x R row tiles, so
+//     i,f,g,o of one (window, unit) sit in the same lane and the cell update is register-local; c never leaves the
+//     wave, h_t goes through a double-buffered LDS image (one barrier per step; lstm2_t_kernel: not even that)
+//     and is written out coalesced, the BatchNorm behind it fused or folded into the next layer's weights.
 #pragma once
 #include "nrv_common.h"        // vector types, buffer loads, activations, ActView
 #include "nrv_cnn.h"           // cnn_kernel
 #include "nrv_lstm1.h"         // lstm1_kernel
 #include "nrv_lstm_f32.h"      // lstm_layer_kernel, lstm_block / lstm_grid
 #include "nrv_lstm_bf16x3.h"   // lstm_split_kernel, lstm_pair_kernel
-#include "nrv_lstm_f16x2.h"    // lstm_h2o_kernel (scaled two-term f16 split, NRV_PREC_F16X2)
-#include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (the same on 16x16x32 tiles)
+#include "nrv_lstm_f16x2.h"    // the scaled two-term f16 split (NRV_PREC_F16X2): types, split2, LstmH2Args
+#include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (192->128 and 256->64 layers of the f16x2 mode, 16x16x32 tiles)
 #include "nrv_lstm2_t.h"       // lstm2_t_kernel (32->64 layer: transposed products, wave-private recurrence)
-#include "nrv_cnn_f16x2.h"     // cnn_h2_kernel (signal branch of the f16x2 mode, convolutions on the VALU), cnn_dense_role
-#include "nrv_cnn_m.h"         // cnn_m_kernel (the same with the 8 -> 8 convolution on the matrix pipe)
 #include "nrv_cnn_r.h"         // cnn_r_kernel (signal branch of the f16x2 mode: conv1 -> conv2 -> dense in registers)
 #include "nrv_head.h"          // head_mlp_kernel, head_mlp_split_kernel, head_final_kernel
 #include "nrv_head_f16x2.h"    // head_h2_kernel (per-timestep MLP + per-window tail, f16x2 mode)

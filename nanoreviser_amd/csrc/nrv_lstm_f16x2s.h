@@ -83,9 +83,6 @@ lstm_h2s_kernel(const LstmH2Args args) {
   __shared__ float cl[CLDS ? NE * NTHREADS : 1];
   __shared__ __attribute__((aligned(16))) float wl[KBL > 0 ? NG * WR * KBL * EPK * 512 : 4];
 
-#if NRV_EXP & 64
-  const unsigned long long exp_c0 = clock64(), exp_w0 = wall_clock64();    // shader clock / 100 MHz (scripts/gpu_clk.sh)
-#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if NRV_STAMP
@@ -342,11 +339,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
               if (tk < TG) {
 #pragma unroll
                 for (int pc = (tk * NGP) / TG; pc < ((tk + 1) * NGP) / TG; ++pc) {
-#if NRV_EXP & 1024                                                  // A/B: two stages per piece, every other tick
-                  if (pc & 1) { gate_stage(gs, Z, himg_w + hw_off, pc / GST, (pc % GST) - 1); gate_stage(gs, Z, himg_w + hw_off, pc / GST, pc % GST); }
-#else
                   gate_stage(gs, Z, himg_w + hw_off, pc / GST, pc % GST);
-#endif
                 }
               } else {
 #pragma unroll
@@ -474,10 +467,6 @@ lstm_h2s_kernel(const LstmH2Args args) {
       for (int i = threadIdx.x; i < kStampWaves * kStampSteps * kStampSlots; i += NTHREADS)
         (&nrv_stamp_buf[H == 128 ? 0 : 1][blockIdx.x][0][0][0])[i] = stamp_lds[i];
   }
-#endif
-#if NRV_EXP & 64
-  if (blockIdx.x == 3 && threadIdx.x == 0 && ((NRV_EXP & 256) ? (H == 64 && KQ0 == 8) : (NRV_EXP & 128) ? (H == 64 && KQ0 == 64) : H == 128))
-    printf("CLK %llu %llu\n", (unsigned long long)(clock64() - exp_c0), (unsigned long long)(wall_clock64() - exp_w0));
 #endif
 }
 

@@ -1,0 +1,65 @@
+"""bench.py's bookkeeping (CPU): the HBM-traffic figure of the JSON line is only printed while the committed PMC pass
+still describes the kernel the library runs, the kernel names bench.py expects are the ones nrv_api.hip launches, and
+the BLAS-grade CPU baseline (oracle/torch_cpu.py) evaluates the same graph as the fp64 oracle."""
+import json
+import os
+import re
+
+import numpy as np
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pmc(tmp_path, **over):
+    rec = {"T": 13, "batch": 4096, "kernel_name": "void nrv::" + bench.KERNEL_SIGNATURE["f16x2"] + "(nrv::LstmH2Args)",
+           "source_sha256_16": bench.kernel_source_sha("f16x2"), "commit": "abc1234", "hbm_bytes_per_launch": 2.8e8,
+           "source": "test"}
+    rec.update(over)
+    (tmp_path / "r99_pmc_lstm3.json").write_text(json.dumps({"f16x2": rec}))
+    return str(tmp_path)
+
+
+def test_traffic_is_printed_only_for_the_kernel_it_was_measured_on(tmp_path):
+    v, src = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path))
+    assert v == 2.8e8 and "r99_pmc_lstm3.json @ abc1234" in src
+    v, src = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, source_sha256_16="0" * 16))
+    assert v is None and "stale" in src                                   # the kernel's source changed since
+    v, src = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, kernel_name="void nrv::lstm_h2o_kernel<32, 16, 128>"))
+    assert v is None and "another kernel" in src
+    rec = json.loads((tmp_path / "r99_pmc_lstm3.json").read_text())["f16x2"]
+    del rec["kernel_name"]
+    (tmp_path / "r99_pmc_lstm3.json").write_text(json.dumps({"f16x2": rec}))
+    v, src = bench.load_traffic(13, 4096, "f16x2", str(tmp_path))
+    assert v is None and "not trusted" in src                             # a file of rounds 1-3: no kernel name
+    assert bench.load_traffic(11, 4096, "f16x2", str(tmp_path))[0] is None   # another shape
+    # whatever is committed under profiles/ either matches the current kernel or is refused with a reason
+    v, src = bench.load_traffic(13, 4096, "f16x2")
+    assert (v is None) == (not src.startswith("profiles/r")) or "@" not in src
+
+
+def test_kernel_signatures_are_what_the_library_launches():
+    api = open(os.path.join(ROOT, "nanoreviser_amd", "csrc", "nrv_api.hip")).read()
+    # 192 -> 128 layer, f16x2: launch_lstm_h2s<KQ0, KQ1, H, R, WR, UH, NBG, NA, KBL, RAW> -> kernel <.., UH, ACT, NBG, NA, KBL, RAW>
+    m = re.search(r"launch_lstm_h2s<32, 16, 128, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), true>\(h, 2,", api)
+    assert m, "the 192->128 launch of the f16x2 mode moved: update bench.KERNEL_SIGNATURE"
+    r, wr, uh, nbg, na, kbl = m.groups()
+    assert bench.KERNEL_SIGNATURE["f16x2"] == f"lstm_h2s_kernel<32, 16, 128, {r}, {wr}, {uh}, 0, {nbg}, {na}, {kbl}, true>"
+    for f in sum(bench.KERNEL_SOURCES.values(), []):
+        assert os.path.exists(os.path.join(ROOT, "nanoreviser_amd", "csrc", f))
+
+
+def test_blas_grade_cpu_baseline_is_the_same_graph(species_models):
+    from oracle import nrv_oracle as O, torch_cpu as TC
+    for sp in ("ecoli", "human"):
+        m1, m2 = species_models[sp]
+        sig, rd = O.synth_windows(24, 11)
+        q1, q2, b1, b2 = O.predict_pair(m1.tensors, m2.tensors, sig, rd, np.float64)
+        p1, p2, a1, a2 = TC.predict_pair(TC.TorchCpuModel(m1.tensors), TC.TorchCpuModel(m2.tensors), sig, rd)
+        assert np.abs(p1 - q1).max() < 1e-4 and np.abs(p2 - q2).max() < 1e-4
+        assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+    m1, m2 = species_models["ecoli"]
+    sig, rd = O.synth_windows(64, 11)
+    r = bench.blas_grade_baseline(m1, m2, 11, sig, rd, 2, 0.5)
+    assert r.get("value", 0) > 0 and r["dtype"] == "f32" and r["cores"] == 2, r

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST5 = os.path.join(GOLD, "fast5")
 
 
-@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("n", [2, 4, 8])
 def test_bench_n_ranks_share_one_device(n):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-device",
                         "--steps", "6", "--warmup", "2", "--prime", "30", "--no-extras", "--no-cpu-baseline"],
@@ -32,6 +32,12 @@ def test_bench_n_ranks_share_one_device(n):
     assert j["n_gpus"] == n and j["world_size"] == n and j["steps"] == 6 and j["scaling"] == "weak"
     assert j["value"] > 0 and abs(j["value"] - n * 4096 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]
     assert "--share-device" in j["config"]["parallelism"] and "gloo" in j["config"]["parallelism"]
+    # every rank's device identity is in the line: n entries, and on this one-GPU box ONE distinct device
+    import torch
+    devs = j["config"]["devices"]
+    assert [x["rank"] for x in devs] == list(range(n)) and j["config"]["world_size"] == n
+    assert j["config"]["distinct_devices"] == min(n, torch.cuda.device_count())
+    assert all(x["pci"] and x["name"] for x in devs)
     mm = j["rank_ms_per_step"]
     assert 0 < mm["min"] <= mm["max"] <= j["ms_per_step"] * 1.0001
     assert j["roofline"]["frac"] > 0 and j["f16x2_range_guard"]["pending_after_timed_region"] == 0
@@ -63,3 +69,24 @@ def test_cli_two_real_workers_on_one_device_match_one_worker(tmp_path):
     for f in names:
         assert open(one + f, "rb").read() == open(two + f, "rb").read(), f
     assert open(two + "failed_reads.txt").read() == ""
+
+
+def test_cli_eight_real_workers_on_one_device_match_one_worker(tmp_path, monkeypatch):
+    """The widest fan-out the command line will see (one worker per GPU of an 8-GPU node), rehearsed on one device:
+    outputs byte-identical to one worker, and the parser processes of all workers together stay within the cores
+    the process may use (each worker used to size its pool for the whole machine)."""
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    for i in range(24):
+        shutil.copy(src[i % 2], d / f"read{i:02d}.fast5")
+    one, eight = str(tmp_path) + "/one/", str(tmp_path) + "/eight/"
+    assert cli.main(["-d", str(d), "-o", one, "-S", "ecoli", "--thread", "4", "--gpus", "1"]) == 0
+    assert cli.main(["-d", str(d), "-o", eight, "-S", "ecoli", "--thread", "100"],
+                    worker_factory=shared_device_factory, world=8) == 0
+    names = sorted(f for f in os.listdir(one) if f.endswith("_out.fasta"))
+    assert len(names) == 24 and names == sorted(f for f in os.listdir(eight) if f.endswith("_out.fasta"))
+    for f in names:
+        assert open(one + f, "rb").read() == open(eight + f, "rb").read(), f
+    assert open(eight + "failed_reads.txt").read() == ""
+    assert 8 * cli.parser_pool_size(100, cli.usable_cores(), 8, 3) <= max(8, cli.usable_cores())

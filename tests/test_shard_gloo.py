@@ -87,6 +87,25 @@ def test_bench_gpus2_typed_as_is_dry_run():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
     assert abs(j["value"] - 2 * 4096 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-3 * j["value"]
+    # every rank's identity reaches rank 0's line (the real run gathers device index / PCI / UUID the same way)
+    rk = j["config"]["ranks"]
+    assert [x["rank"] for x in rk] == [0, 1] and len({x["pid"] for x in rk}) == 2 and rk[0]["shard"] != rk[1]["shard"]
+
+
+def test_bench_gpus8_dry_run_eight_ranks():
+    """The driver's widest launch, rehearsed on CPU: eight ranks, one JSON line, eight distinct shards."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--batch", "512",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["world_size"] == 8 and j["config"]["world_size"] == 8
+    rk = j["config"]["ranks"]
+    assert [x["rank"] for x in rk] == list(range(8)) and len({tuple(x["shard"]) for x in rk}) == 8
 
 
 def test_bench_refuses_world_size_mismatch():

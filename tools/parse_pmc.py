@@ -41,6 +41,7 @@ def short(name):
 
 def main(src, dst):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    full = {}
     for f in sorted(glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), recursive=True)):
         rows = list(csv.DictReader(open(f)))
         # skip warm-up dispatches: keep the last 8 per kernel (bench --steps 8)
@@ -48,6 +49,7 @@ def main(src, dst):
         for r in rows:
             k = short(r["Kernel_Name"])
             if k:
+                full[k] = r["Kernel_Name"]
                 per[(k, r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for (k, c), vals in per.items():
             vals.sort()
@@ -58,6 +60,7 @@ def main(src, dst):
     for k, cs in acc.items():
         out[k] = {c: s / n for c, (s, n) in cs.items()}
         o = out[k]
+        o["kernel_name"] = full.get(k, "")
         if "FETCH_SIZE" in o:
             o["hbm_read_bytes_corrected"] = o["FETCH_SIZE"] * 1024 * 2
         if "WRITE_SIZE" in o:
@@ -68,7 +71,7 @@ def main(src, dst):
             o["l2_hit_rate"] = o["TCC_HIT_sum"] / max(o["TCC_HIT_sum"] + o["TCC_MISS_sum"], 1)
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     for k in sorted(out):
-        print(k, json.dumps({a: round(b, 1) for a, b in sorted(out[k].items())}))
+        print(k, json.dumps({a: (round(b, 1) if isinstance(b, float) else b) for a, b in sorted(out[k].items())}))
 
 
 if __name__ == "__main__":
