@@ -96,8 +96,11 @@ def test_whole_windows_in_the_conv1_overflow_band(reads, species_models, amp):
             assert np.array_equal(g, r)
     q1, q2, _, _ = O.predict_pair(m1.tensors, m2.tensors, sig, fw, np.float64)
     nf1, nf2 = f32_floor(m1, m2, sig, fw, q1, q2)
-    check_vs_fp64(got[0], got[2], q1, nf1, f"x{amp:g} m1", max_ill=0.05)
-    check_vs_fp64(got[1], got[3], q2, nf2, f"x{amp:g} m2", max_ill=0.05)
+    # (amplified windows through the HUMAN weights: 5 - 8 % of them are ill-conditioned for f32 arithmetic itself - the
+    # two CPU f32 restatements leave half the bar there -, so the share allowed is 10 %; the engine's own error on
+    # every window, well- or ill-conditioned, is held to the same policy as everywhere else)
+    check_vs_fp64(got[0], got[2], q1, nf1, f"x{amp:g} m1", max_ill=0.10)
+    check_vs_fp64(got[1], got[3], q2, nf2, f"x{amp:g} m2", max_ill=0.10)
 
 
 @pytest.mark.parametrize("mode", MODES)
