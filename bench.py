@@ -327,6 +327,7 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
             "affinity": {"mask": _mask_str(aff), "n": len(aff), "os_cpu_count": os.cpu_count(),
                          "cgroup_cpu_quota": quota},
             "blas_grade": blas,
+            "host_capacity": host_capacity(cores),
             "host_stage_us_per_base": host_stage_us_per_base(),
             "reference_keras_tf": ref,
             "note": "kind 'port': the reference's path is Python on keras 2.2.4 / tensorflow 1.12, which cannot be "
@@ -351,6 +352,78 @@ def kernel_source_sha(precision):
         with open(os.path.join(ROOT, "nanoreviser_amd", "csrc", f), "rb") as fp:
             hsh.update(fp.read())
     return hsh.hexdigest()[:16]
+
+
+class NullEngine:
+    """The engine's call surface with no device behind it: every window comes back as class 0 / 0.  What remains of a
+    `cli.process_files` run is the HOST side of the command line - fast5 parsing, event collapse, statistics, packing,
+    merge, record, file write - i.e. the rate at which this host can feed GPUs."""
+    T = 11
+
+    @staticmethod
+    def pack_bundle(raw, starts, feat, meta, T):
+        from nanoreviser_amd.engine import Reviser
+        return Reviser.pack_bundle(raw, starts, feat, meta, T)
+
+    def run_packed_raw(self, packed):
+        out = packed[-1]
+        for o in out:
+            o.fill(0)
+        return out
+
+    def predict_reads_raw(self, raws, starts, feats, shifts, scales):
+        n = max(sum(len(f) for f in feats) - self.T, 0)
+        return (np.zeros((n, 6), np.float32), np.zeros((n, 5), np.float32), np.zeros(n, np.int8), np.zeros(n, np.int8))
+
+    def predict_read(self, sig_ev, feat_ev):
+        return self.predict_reads_raw(None, None, [feat_ev], None, None)
+
+    def close(self):
+        pass
+
+
+def host_capacity(cores, reps=400):
+    """bases/s through `cli.process_files` with a NullEngine on the two committed fixture reads x reps, at 1, 4 and 16
+    parser workers (capped at the cores this process may use): how many bases per second the host stage delivers."""
+    import shutil
+    import tempfile
+    from nanoreviser_amd import cli
+    src = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden", "fast5")) if f.endswith(".fast5"))
+    if not src:
+        return {"error": "no fixture fast5 files"}
+    tmp = tempfile.mkdtemp(prefix="nrv_hostcap_")
+    try:
+        din = os.path.join(tmp, "in")
+        os.makedirs(din)
+        names = []
+        for i in range(reps):
+            for j, f in enumerate(src):
+                fn = f"r{i:04d}_{j}.fast5"
+                try:
+                    os.link(os.path.join(ROOT, "tests", "golden", "fast5", f), os.path.join(din, fn))
+                except OSError:
+                    shutil.copy(os.path.join(ROOT, "tests", "golden", "fast5", f), os.path.join(din, fn))
+                names.append(fn)
+        out = {"unit": "bases/s", "reads": len(names),
+               "what": "cli.process_files with an engine that computes nothing: fast5 parse, event collapse, statistics, "
+                       "packing, merge, FASTA write of the two committed fixture reads x %d" % reps}
+        for w in [-min(16, cores)] + sorted({1, min(4, cores), min(16, cores)}):
+            args = cli.get_args(["-d", din + "/", "-o", os.path.join(tmp, f"out{w}") + "/", "-S", "ecoli", "--thread", str(abs(w))])
+            os.makedirs(args.output_dir, exist_ok=True)
+            if w < 0:       # untimed: the pool threads' first calls pay for their malloc arenas and the page cache
+                cli.process_files(args, names[:min(len(names), 40 * abs(w))], NullEngine(), lambda m: None)
+                continue
+            t0 = time.perf_counter()
+            st = cli.process_files(args, names, NullEngine(), lambda m: None)
+            dt = time.perf_counter() - t0
+            out[f"workers_{w}"] = st["bases"] / dt
+            out["host_stage"] = st.get("host_stage")
+            out[f"host_ms_per_read_workers_{w}"] = st["host_s"] / max(st["reads"], 1) * 1e3
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def blas_grade_baseline(m1, m2, T, sig, rd, cores, budget_s):

@@ -36,6 +36,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 from . import h5lite
+from . import hostlib
 from . import hoststage as hs
 from .shard import shard_reads
 from .weights import load_model
@@ -203,10 +204,18 @@ def revise_many(reviser, rts, want_qual: bool = True):
     return [_finish_read(reviser.T, rt, *c, want_qual=want_qual) for rt, c in zip(rts, predict_many(reviser, rts))]
 
 
-def _load_one(job):
-    """Worker-process side of the host stage: fast5 -> per-event device inputs (picklable)."""
-    path, fn, group, subgroup = job
+def _load_one(job, native: bool = True):
+    """Worker side of the host stage: fast5 -> per-event device inputs (picklable).  The file goes through the native
+    reader (libnanorev_host.so: nrvh_load_fast5, one C call with the GIL released) when that is built and knows the
+    file's HDF5 subset; anything else - and every failure - through the Python host stage, which is the definition of
+    the numbers and words the errors."""
+    path, fn, group, subgroup = job[:4]
     t0 = time.perf_counter()
+    if native:
+        rc, o = hostlib.load_fast5(path, group, subgroup, want_fastq=(job[4] if len(job) > 4 else True))
+        if rc == hostlib.OK:
+            rt = hs.RawReadTensors(o["raw"], o["starts"], o["feat"], o["bases"], o["shift"], o["scale"])
+            return fn, rt, o["fastq"], None, time.perf_counter() - t0
     try:
         rd, fq = parse_read(path, group, subgroup)
     except Exception as e:                           # broken file: nothing to fall back to
@@ -235,9 +244,48 @@ def _load_bundle(jobs):
     arrays nor concatenates them: a bundle is four big arrays.  Returns (entries, bundle): entries are
     `_load_one`'s tuples, with the tensors of bundled reads replaced by a `_LightRead`; bundle is None when no read
     qualified."""
+    t0 = time.perf_counter()
+    nb = hostlib.load_bundle([j[0] for j in jobs], jobs[0][2], jobs[0][3], want_fastq=(jobs[0][4] if len(jobs[0]) > 4 else True)) \
+        if jobs and all(j[2:] == jobs[0][2:] for j in jobs) else None
+    if nb is not None and int((nb["status"] == hostlib.OK).sum()) > 0:
+        # ONE native call for the whole task: the reads it took are already concatenated; the others (a layout the native
+        # reader does not know, a broken file) go through the Python host stage one by one
+        dt = (time.perf_counter() - t0) / len(jobs)
+        entries, good, eo = [], [], 0
+        for i, j in enumerate(jobs):
+            if nb["status"][i] == hostlib.OK:
+                el = int(nb["meta"][i, 1])
+                entries.append((j[1], _LightRead(nb["bases"][eo:eo + el], el), nb["fastq"][i], None, dt))
+                good.append(i)
+                eo += el
+            else:
+                entries.append(tuple(_load_one(j, native=False)))
+        if any(isinstance(e[1], hs.RawReadTensors) for e in entries):
+            # a Python-path read would have to be spliced into the middle of the concatenation: rare enough to give up
+            # the bundle's shortcut for this task (each read then travels on its own, as without a pool)
+            out, eo, ro = [], 0, 0
+            for i, e in enumerate(entries):
+                if i in good:
+                    rl, el, sh, sc = nb["meta"][i]
+                    rl, el = int(rl), int(el)
+                    rt = hs.RawReadTensors(nb["raw"][ro:ro + rl], nb["starts"][eo:eo + el], nb["feat"][eo:eo + el],
+                                           nb["bases"][eo:eo + el], float(sh), float(sc))
+                    out.append((e[0], rt, e[2], None, e[4]))
+                    ro += rl
+                    eo += el
+                else:
+                    out.append(e)
+            return _bundle_of(out)
+        bundle = {"idx": good, "raw": nb["raw"], "starts": nb["starts"], "feat": nb["feat"],
+                  "meta": np.ascontiguousarray(nb["meta"][good])}
+        return entries, bundle
+    return _bundle_of([_load_one(j) for j in jobs])
+
+
+def _bundle_of(loaded):
+    """`_load_one` tuples -> (entries, bundle): the raw reads among them concatenated into the arrays of one device call."""
     entries, good = [], []
-    for j in jobs:
-        fn, rt, fq, err, dt = _load_one(j)
+    for fn, rt, fq, err, dt in loaded:
         if err is None and isinstance(rt, hs.RawReadTensors):
             good.append(len(entries))
         entries.append([fn, rt, fq, err, dt])
@@ -296,6 +344,20 @@ def _finish_in_worker(spec, T, fn, bases, a1, a2, qc):
                         + np.repeat(edge, len(codes) - off - n).tobytes()).decode("ascii")
         write_read(spec, fn, seq, qual)
         return len(seq), None
+    except Exception as e:
+        return 0, repr(e)
+
+
+def _finish_native(spec, T, fn, bases, a1, a2, qc):
+    """`_finish_in_worker` through libnanorev_host.so (nrvh_finish_read: merge, record, temporary + rename in one C call
+    with the GIL released) - for the THREAD pool of process_files.  Same return value."""
+    try:
+        os.makedirs(spec.output_dir, exist_ok=True)
+        nb = hostlib.finish_read(bases, a1, a2, T, qc, fn.split("/")[-1].replace(" ", "|||"),
+                                 out_name(spec.output_dir, fn, spec.output_format), spec.output_format == "fastq")
+        if nb is None:
+            return _finish_in_worker(spec, T, fn, bases, a1, a2, qc)
+        return nb, None
     except Exception as e:
         return 0, repr(e)
 
@@ -384,8 +446,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     stats_lock = threading.Lock()
     nworkers = parser_pool_size(int(args.thread), usable_cores(), gpu_workers, len(files))
     stats["parser_workers"] = nworkers
-    jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup)
-            for fn in files]
+    jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup,
+             args.output_format == "fastq") for fn in files]
 
     # Files per worker task: one task = one device call (>= kBatchEvents events at ~6.5 k events per read); the
     # worker hands back the reads of a task already concatenated (`_load_bundle`).
@@ -395,7 +457,22 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     per_task = max(1, min(32, kBatchEvents // 6500, -(-len(jobs) // (2 * nworkers))))
 
     pool = None
-    if nworkers > 1 and len(files) >= 4:
+    # With the native host stage (libnanorev_host.so) a task is ONE C call per bundle of files and one per finished read,
+    # both with the GIL released: the pool is THREADS of this process - nothing is spawned, nothing is pickled, a bundle's
+    # arrays are handed over by reference.  Without the library (or NRV_HOST_THREADS=0) the same tasks run in worker
+    # PROCESSES on the Python host stage, as in round 3.
+    native_threads = hostlib.load() is not None and os.environ.get("NRV_HOST_THREADS", "1") != "0"
+    stats["host_stage"] = "native, threads" if native_threads else ("python, processes" if hostlib.load() is None else "native, processes")
+    old_switch = None
+    if nworkers > 1 and len(files) >= 4 and native_threads:
+        from concurrent.futures import ThreadPoolExecutor as _TPE
+        pool = _TPE(nworkers)
+        # A pool thread coming back from its C call needs the GIL for ~0.1 ms of bookkeeping; with CPython's default
+        # switch interval (5 ms) it waited that long behind whichever thread held it, and four parser threads delivered
+        # what one does (r04: 3.2 M bases/s with 1, 4 or 8 threads; 10 / 13 M with 4 / 8 at 0.2 ms).  Restored on return.
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)
+    elif nworkers > 1 and len(files) >= 4:
         import multiprocessing as mp
         # The workers never call BLAS; without a cap every one of them starts, at `import numpy`, an OpenBLAS pool sized
         # for the machine (256 CPUs on the GPU boxes, 16 in the cgroup): the first parsed reads came back after 0.73 s
@@ -464,8 +541,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                 if pool is not None:
                     p1, p2, a1, a2 = c
                     qc = phred_chars(p1, p2, a1, a2) if want_qual and len(a1) else None
-                    finishing.append((pool.submit(_finish_in_worker, spec, reviser.T, fn, np.asarray(rt.bases),
-                                                  np.asarray(a1), np.asarray(a2), qc), fn, rt, fq))
+                    finishing.append((pool.submit(_finish_native if native_threads else _finish_in_worker, spec, reviser.T, fn,
+                                                  np.asarray(rt.bases), np.asarray(a1), np.asarray(a2), qc), fn, rt, fq))
                     continue
                 seq, qual = _finish_read(reviser.T, rt, *c, want_qual=want_qual)
                 write_read(args, fn, seq, qual)
@@ -531,6 +608,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     inflight = deque()
     import contextlib
     with contextlib.ExitStack() as stack:
+        if old_switch is not None:
+            stack.callback(lambda: sys.setswitchinterval(old_switch))
         if pool is not None:                          # whatever happens below, the parser pool does not outlive us
             stack.callback(lambda: pool.shutdown(wait=False, cancel_futures=True))
         eng = stack.enter_context(ThreadPoolExecutor(n_eng))

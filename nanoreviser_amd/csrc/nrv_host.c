@@ -7,7 +7,7 @@
 
 #include "../../include/nanorev_host.h"
 
-int nrvh_abi_version(void) { return 1; }
+int nrvh_abi_version(void) { return 2; }
 
 /* NumPy's float64 add.reduce over a contiguous run (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum):
  * fewer than 8 values are added in order; up to 128 go through eight running sums combined as
