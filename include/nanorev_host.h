@@ -87,6 +87,13 @@ void nrvh_free_bundle(nrvh_bundle* b);
 int nrvh_finish_read(const char* bases, int64_t n_ev, const int8_t* a1, const int8_t* a2, int64_t n_win, int T,
                      const uint8_t* qc, const char* name, const char* dst, int fastq, int64_t* n_written);
 
+/* nrvh_finish_read for every read of ONE device call: bases / a1 / a2 / qc are the call's concatenated arrays (read r
+ * has ev_len[r] bases and max(ev_len[r] - T, 0) windows; its window i is window e0 + i of the call, e0 = the bases in
+ * front of it; n_win_total windows in all).  status[r] / n_written[r] per read; a failing read does not stop the others. */
+int nrvh_finish_bundle(const char* bases, const int64_t* ev_len, int n_reads, const int8_t* a1, const int8_t* a2,
+                       int64_t n_win_total, int T, const uint8_t* qc, const char* const* names, const char* const* dsts,
+                       int fastq, int64_t* n_written, int32_t* status);
+
 /* ABI version of this header (2). */
 int nrvh_abi_version(void);
 

@@ -277,7 +277,7 @@ def _load_bundle(jobs):
                     out.append(e)
             return _bundle_of(out)
         bundle = {"idx": good, "raw": nb["raw"], "starts": nb["starts"], "feat": nb["feat"],
-                  "meta": np.ascontiguousarray(nb["meta"][good])}
+                  "meta": np.ascontiguousarray(nb["meta"][good]), "bases": nb["bases"]}
         return entries, bundle
     return _bundle_of([_load_one(j) for j in jobs])
 
@@ -360,6 +360,20 @@ def _finish_native(spec, T, fn, bases, a1, a2, qc):
         return nb, None
     except Exception as e:
         return 0, repr(e)
+
+
+def _finish_bundle_native(spec, T, fns, bases, ev_len, a1, a2, qc):
+    """All reads of one device call through nrvh_finish_bundle (one C call, GIL released): [(bases written, error)]."""
+    try:
+        os.makedirs(spec.output_dir, exist_ok=True)
+        r = hostlib.finish_bundle(bases, ev_len, a1, a2, T, qc, [fn.split("/")[-1].replace(" ", "|||") for fn in fns],
+                                  [out_name(spec.output_dir, fn, spec.output_format) for fn in fns], spec.output_format == "fastq")
+        if r is None:
+            raise RuntimeError("libnanorev_host.so went away")
+        nw, st = r
+        return [(int(n), None if c == hostlib.OK else f"native finisher: error {int(c)}") for n, c in zip(nw, st)]
+    except Exception as e:
+        return [(0, repr(e))] * len(fns)
 
 
 def usable_cores() -> int:
@@ -551,17 +565,32 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
                 fallback(fn, rt, fq, e)
 
     def collect_finished(block):
-        """Results of the pooled merges (main thread)."""
+        """Results of the pooled merges (main thread).  An entry is one read, or (fn is a list) all reads of a device call."""
         while finishing and (block or finishing[0][0].done()):
             fut, fn, rt, fq = finishing.pop(0)
+            many = isinstance(fn, list)
             try:
-                nb, err = fut.result()
+                res = fut.result()
             except Exception as e:                    # the pool broke (a parser process died)
-                nb, err = 0, repr(e)
-            if err is None:
-                finished(fn, nb)
-            else:
-                fallback(fn, rt, fq, err)
+                res = [(0, repr(e))] * len(fn) if many else (0, repr(e))
+            for (nb, err), f1, r1, q1 in (zip(res, fn, rt, fq) if many else [(res, fn, rt, fq)]):
+                if err is None:
+                    finished(f1, nb)
+                else:
+                    fallback(f1, r1, q1, err)
+
+    def finish_bundle(batch, bundle, outs):
+        """Finisher thread, native host stage: merge + record + file of ALL reads of a device call as one pool task."""
+        reviser = box["rv"]
+        try:
+            p1, p2, a1, a2 = outs
+            qc = phred_chars(p1, p2, a1, a2) if want_qual and len(a1) else None
+            fut = pool.submit(_finish_bundle_native, spec, reviser.T, [fn for fn, _, _ in batch], bundle["bases"],
+                              bundle["meta"][:, 1].astype(np.int64), a1, a2, qc)
+            finishing.append((fut, [fn for fn, _, _ in batch], [rt for _, rt, _ in batch], [fq for _, _, fq in batch]))
+        except Exception as e:
+            for fn, rt, fq in batch:
+                fallback(fn, rt, fq, e)
 
     def run_batch(batch, packed=None, bundle=None):
         """Engine thread: one device call for the batch; merging and writing go to the finisher."""
@@ -577,20 +606,30 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         if trace is not None:
             ti = len(trace)
             trace.append(("call", t0 - t_start, 0.0))
-        rts = _bundle_reads(bundle) if bundle is not None else [rt for _, rt, _ in batch]
+        rts = None
+
+        def reads():                                  # the reads as tensors: only the per-read paths need them
+            return _bundle_reads(bundle) if bundle is not None else [rt for _, rt, _ in batch]
         try:
             if bundle is not None and packed is not None:
                 p1, p2, a1, a2 = reviser.run_packed_raw(packed)
+                if native_threads and pool is not None and "bases" in bundle and len(bundle["bases"]) == int(bundle["meta"][:, 1].sum()):
+                    with stats_lock:
+                        stats["engine_s"] += time.perf_counter() - t0
+                    if ti is not None:
+                        trace[ti] = ("call", t0 - t_start, time.perf_counter() - t0)
+                    return fin.submit(finish_bundle, batch, bundle, (p1, p2, a1, a2))
                 calls, e0, T = [], 0, reviser.T
                 for rl, el, _, _ in bundle["meta"]:        # window i of a read == window e0 + i of the bundle
                     n = max(int(el) - T, 0)
                     calls.append((p1[e0:e0 + n], p2[e0:e0 + n], a1[e0:e0 + n], a2[e0:e0 + n]))
                     e0 += int(el)
             else:
+                rts = reads()
                 calls = predict_many(reviser, rts, packed)
         except Exception:
             calls = []
-            for rt in rts:                           # isolate the failing read(s)
+            for rt in (rts if rts is not None else reads()):   # isolate the failing read(s)
                 try:
                     calls.append(predict_one(reviser, rt))
                 except Exception as e:

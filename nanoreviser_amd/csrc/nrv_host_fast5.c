@@ -721,3 +721,23 @@ int nrvh_finish_read(const char* bases, int64_t n_ev, const int8_t* a1, const in
   if (n_written) *n_written = nseq;
   return NRVH_OK;
 }
+
+/* The reads of ONE device call at once: bases / a1 / a2 / qc are the call's concatenated arrays (read r has ev_len[r]
+ * bases; its window i is window e0 + i of the call, e0 the bases in front of it; it has max(ev_len[r] - T, 0) windows).
+ * status[r] = NRVH_OK or the error of that read alone (the others are still written). */
+int nrvh_finish_bundle(const char* bases, const int64_t* ev_len, int n_reads, const int8_t* a1, const int8_t* a2,
+                       int64_t n_win_total, int T, const uint8_t* qc, const char* const* names, const char* const* dsts,
+                       int fastq, int64_t* n_written, int32_t* status) {
+  if (!bases || !ev_len || n_reads < 0 || !names || !dsts || !status || T < 1) return NRVH_E_ARG;
+  int64_t e0 = 0;
+  for (int r = 0; r < n_reads; ++r) {
+    const int64_t el = ev_len[r], n = el - T > 0 ? el - T : 0;
+    if (el < 0 || (n > 0 && e0 + n > n_win_total)) { status[r] = NRVH_E_ARG; e0 += el > 0 ? el : 0; continue; }
+    int64_t nw = 0;
+    status[r] = nrvh_finish_read(bases + e0, el, a1 ? a1 + e0 : 0, a2 ? a2 + e0 : 0, n, T, qc ? qc + e0 : 0, names[r], dsts[r],
+                                 fastq, &nw);
+    if (n_written) n_written[r] = nw;
+    e0 += el;
+  }
+  return NRVH_OK;
+}

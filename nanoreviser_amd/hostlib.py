@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnanorev_host.so")
 SYMBOLS = ["nrvh_abi_version", "nrvh_event_stats", "nrvh_load_fast5", "nrvh_free_read", "nrvh_load_bundle",
-           "nrvh_free_bundle", "nrvh_finish_read"]
+           "nrvh_free_bundle", "nrvh_finish_read", "nrvh_finish_bundle"]
 _lib = None
 _tried = False
 
@@ -60,6 +60,9 @@ def load() -> Optional[C.CDLL]:
         lib.nrvh_finish_read.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
         lib.nrvh_finish_read.restype = C.c_int
+        lib.nrvh_finish_bundle.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                           C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_void_p]
+        lib.nrvh_finish_bundle.restype = C.c_int
         lib.nrvh_event_stats.argtypes = [C.POINTER(C.c_int16), C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.nrvh_event_stats.restype = C.c_int
@@ -134,32 +137,53 @@ def load_bundle(paths, group: str, subgroup: str, want_fastq: bool = True):
         return None
     n = len(paths)
     arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
-    b = _NativeBundle()
+    mem = _BundleMem(lib)
+    b = mem.b
     rc = lib.nrvh_load_bundle(arr, n, group.encode(), subgroup.encode(), 1 if want_fastq else 0, C.byref(b))
     if rc != OK:
         return None
-    try:
-        E = int(b.n_ev)
-        status = _arr(b.status, n, np.int32)
-        errs = C.string_at(b.errors, n * ERR_LEN)
+    mem.live = True
+    E = int(b.n_ev)
+    status = _arr(b.status, n, np.int32)
+    errs = C.string_at(b.errors, n * ERR_LEN) if (status != OK).any() else b""
+    fastq = [None] * n
+    if want_fastq:
         foff = _arr(b.fastq_off, n + 1, np.int64)
         ftxt = C.string_at(b.fastq, int(foff[n])) if int(foff[n]) else b""
-        fastq = []
         for i in range(n):
-            if status[i] != OK or foff[i] < 0:
-                fastq.append(None)
-            else:
+            if status[i] == OK and foff[i] >= 0:
                 j = i + 1
                 while j < n and foff[j] < 0:
                     j += 1
-                fastq.append(ftxt[int(foff[i]):int(foff[j])].decode("utf8", "replace"))
-        return {"status": status,
-                "errors": [errs[i * ERR_LEN:(i + 1) * ERR_LEN].split(b"\0")[0].decode("utf8", "replace") for i in range(n)],
-                "raw": _arr(b.raw, int(b.n_raw), np.int16), "starts": _arr(b.starts, E, np.int32),
-                "feat": _arr(b.feat, E * 6, np.float32).reshape(E, 6), "bases": _arr(b.bases, E, "S1"),
-                "meta": _arr(b.meta, n * 4, np.float64).reshape(n, 4), "fastq": fastq}
-    finally:
-        lib.nrvh_free_bundle(C.byref(b))
+                fastq[i] = ftxt[int(foff[i]):int(foff[j])].decode("utf8", "replace")
+    # the big arrays are NOT copied: they are views of the C buffers, which live until the last view is gone
+    return {"status": status,
+            "errors": [errs[i * ERR_LEN:(i + 1) * ERR_LEN].split(b"\0")[0].decode("utf8", "replace") if errs else "" for i in range(n)],
+            "raw": mem.view(b.raw, int(b.n_raw), np.int16), "starts": mem.view(b.starts, E, np.int32),
+            "feat": mem.view(b.feat, E * 6, np.float32).reshape(E, 6), "bases": mem.view(b.bases, E, "S1"),
+            "meta": _arr(b.meta, n * 4, np.float64).reshape(n, 4), "fastq": fastq}
+
+
+class _BundleMem:
+    """Owner of one nrvh_bundle's C buffers: released when the last array that views them has gone."""
+
+    def __init__(self, lib):
+        self.lib, self.b, self.live = lib, _NativeBundle(), False
+
+    def view(self, ptr, count, dtype):
+        if not count:
+            return np.zeros(0, dtype)
+        nbytes = count * np.dtype(dtype).itemsize
+        buf = (C.c_char * nbytes).from_address(C.addressof(ptr.contents))
+        buf._owner = self                               # numpy keeps `buf` as the array's base, `buf` keeps us
+        a = np.frombuffer(buf, dtype=dtype)
+        a.flags.writeable = False
+        return a
+
+    def __del__(self):
+        if self.live:
+            self.live = False
+            self.lib.nrvh_free_bundle(C.byref(self.b))
 
 
 def finish_read(bases, a1, a2, T: int, qc, name: str, dst: str, fastq: bool):
@@ -183,3 +207,27 @@ def finish_read(bases, a1, a2, T: int, qc, name: str, dst: str, fastq: bool):
     if rc != OK:
         raise OSError(f"finish_read: cannot write {dst}")
     return int(nw.value)
+
+
+def finish_bundle(bases, ev_len, a1, a2, T: int, qc, names, dsts, fastq: bool):
+    """`finish_read` for all reads of one device call in ONE native call (bases S1[E] concatenated, ev_len int64[R],
+    a1 / a2 int8[E - T] and qc uint8[E - T] | None as the call returned them).  Returns (n_written int64[R],
+    status int32[R]); None without the library."""
+    lib = load()
+    if lib is None:
+        return None
+    bb = np.ascontiguousarray(bases, dtype="S1")
+    el = np.ascontiguousarray(ev_len, dtype=np.int64)
+    x1, x2 = np.ascontiguousarray(a1, dtype=np.int8), np.ascontiguousarray(a2, dtype=np.int8)
+    q = np.ascontiguousarray(qc, dtype=np.uint8) if qc is not None else None
+    R = len(el)
+    if int(el.sum()) != len(bb) or len(x1) != len(x2) or (q is not None and len(q) != len(x1)) or len(names) != R or len(dsts) != R:
+        raise ValueError("finish_bundle: arrays do not match the read table")
+    nm = (C.c_char_p * R)(*[n.encode("utf8") for n in names])
+    ds = (C.c_char_p * R)(*[os.fsencode(d) for d in dsts])
+    nw, st = np.zeros(R, np.int64), np.zeros(R, np.int32)
+    rc = lib.nrvh_finish_bundle(bb.ctypes.data, el.ctypes.data, R, x1.ctypes.data, x2.ctypes.data, len(x1), int(T),
+                                q.ctypes.data if q is not None else None, nm, ds, 1 if fastq else 0, nw.ctypes.data, st.ctypes.data)
+    if rc != OK:
+        raise ValueError("finish_bundle: bad arguments")
+    return nw, st

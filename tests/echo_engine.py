@@ -41,6 +41,30 @@ class EchoEngine:
         return self.predict_read(sig, np.concatenate(feats))
 
 
+class PackedEcho(EchoEngine):
+    """EchoEngine with the packed raw-read surface of engine.Reviser (pack_bundle / run_packed_raw): what the command
+    line's native host stage drives - one call per bundle of reads, outputs for the concatenated event range."""
+
+    @staticmethod
+    def pack_bundle(raw, starts, feat, meta, T):
+        from nanoreviser_amd.engine import Reviser
+        return Reviser.pack_bundle(raw, starts, feat, meta, T)
+
+    def run_packed_raw(self, packed):
+        raw, st, feat, descs, nr, N, (p1, p2, a1, a2) = packed
+        self.calls += 1
+        if self.fail_marker is not None and np.array_equal(feat[0], self.fail_marker):
+            raise RuntimeError("injected engine failure")
+        n = max(N - self.T, 0)
+        col = np.rint(feat[:, 0] * 300).astype(int)
+        lab = np.select([col == 250, col == 180, col == 100, col == 30], [5, 4, 3, 2])
+        a1[:] = lab[5:5 + n]
+        a2[:] = a1 - 1
+        p1[:] = np.eye(6, dtype=np.float32)[a1] * 0.9 + 0.1 / 6
+        p2[:] = np.eye(5, dtype=np.float32)[a2] * 0.9 + 0.1 / 5
+        return p1, p2, a1, a2
+
+
 def echo_factory(args, device):
     return EchoEngine()
 

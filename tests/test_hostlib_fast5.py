@@ -21,7 +21,7 @@ import pytest
 from conftest import GOLD
 from nanoreviser_amd import cli, hostlib
 from nanoreviser_amd import hoststage as hs
-from echo_engine import EchoEngine
+from echo_engine import EchoEngine, PackedEcho
 
 FAST5 = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")))
 REF5 = sorted(glob.glob("/root/reference/unitest/test_data/fast5/*.fast5"))     # build container only
@@ -171,11 +171,16 @@ def test_cli_threads_native_equals_processes_python(tmp_path, monkeypatch, fmt):
             monkeypatch.setenv(k, v)
         monkeypatch.setattr(hostlib, "_tried", False)
         monkeypatch.setattr(hostlib, "_lib", None)
-        out = str(tmp_path / tag) + "/"
-        assert cli.main(["-d", str(d), "-o", out, "-F", fmt, "-S", "ecoli", "--thread", "3"],
-                        reviser_factory=lambda a, dev: EchoEngine()) == 0
-        outs[tag] = {f: open(out + f, "rb").read() for f in sorted(os.listdir(out))}
+        for eng_tag, eng in (("", EchoEngine), ("_packed", PackedEcho)):
+            out = str(tmp_path / (tag + eng_tag)) + "/"
+            assert cli.main(["-d", str(d), "-o", out, "-F", fmt, "-S", "ecoli", "--thread", "3"],
+                            reviser_factory=lambda a, dev: eng()) == 0
+            outs[tag + eng_tag] = {f: open(out + f, "rb").read() for f in sorted(os.listdir(out))}
     monkeypatch.setattr(hostlib, "_tried", False)
     monkeypatch.setattr(hostlib, "_lib", None)
     assert len(outs["native"]) == 13 and outs["native"]["failed_reads.txt"].split() == [b"broken.fast5"]
-    assert outs["native"] == outs["python"] == outs["native_procs"]
+    # the echo engines return every read unchanged: whatever the pool (threads / processes), the reader (C / Python) and
+    # the finisher (per read, per device call in one C call, Python), the files are the same bytes
+    for k, v in outs.items():
+        assert v == outs["native"], k
+    assert len(outs) == 6
