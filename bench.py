@@ -414,7 +414,11 @@ def host_capacity(cores, reps=400):
                 cli.process_files(args, names[:min(len(names), 40 * abs(w))], NullEngine(), lambda m: None)
                 continue
             t0 = time.perf_counter()
-            st = cli.process_files(args, names, NullEngine(), lambda m: None)
+            cap, cli.kNativePoolMax = cli.kNativePoolMax, 64      # this leg measures what w workers deliver: no cap
+            try:
+                st = cli.process_files(args, names, NullEngine(), lambda m: None)
+            finally:
+                cli.kNativePoolMax = cap
             dt = time.perf_counter() - t0
             out[f"workers_{w}"] = st["bases"] / dt
             out["host_stage"] = st.get("host_stage")

@@ -407,11 +407,17 @@ def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
     os.replace(tmp, dst)
 
 
-def parser_pool_size(threads: int, cores: int, gpu_workers: int, n_files: int) -> int:
-    """Parser processes of ONE GPU worker: --thread, capped at this worker's share of the cores the process may use
-    (cores // gpu_workers, at least 1), at 32 and at the number of files."""
+kNativePoolMax = 4      # parser THREADS per GPU worker with the native host stage: 4 deliver 23 M bases/s (r04, 16-core cgroup),
+                        # twice what one GPU takes; more only take the GIL from the engine thread (r04, 4000 reads end to
+                        # end: 2 / 4 / 8 / 16 threads = 11.2 / 11.3 / 10.2 / 9.3 M bases/s)
+
+
+def parser_pool_size(threads: int, cores: int, gpu_workers: int, n_files: int, native: bool = False) -> int:
+    """Parser workers of ONE GPU worker: --thread, capped at this worker's share of the cores the process may use
+    (cores // gpu_workers, at least 1), at 32 (processes on the Python host stage) or kNativePoolMax (threads on the
+    native one) and at the number of files."""
     share = max(1, cores // max(1, gpu_workers))
-    return max(1, min(int(threads), share, 32, max(1, n_files)))
+    return max(1, min(int(threads), share, kNativePoolMax if native else 32, max(1, n_files)))
 
 
 def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None],
@@ -458,7 +464,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         free.put(reviser)
         engines.append(reviser)
     stats_lock = threading.Lock()
-    nworkers = parser_pool_size(int(args.thread), usable_cores(), gpu_workers, len(files))
+    native_threads = hostlib.load() is not None and os.environ.get("NRV_HOST_THREADS", "1") != "0"
+    nworkers = parser_pool_size(int(args.thread), usable_cores(), gpu_workers, len(files), native=native_threads)
     stats["parser_workers"] = nworkers
     jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup,
              args.output_format == "fastq") for fn in files]
@@ -475,7 +482,6 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     # both with the GIL released: the pool is THREADS of this process - nothing is spawned, nothing is pickled, a bundle's
     # arrays are handed over by reference.  Without the library (or NRV_HOST_THREADS=0) the same tasks run in worker
     # PROCESSES on the Python host stage, as in round 3.
-    native_threads = hostlib.load() is not None and os.environ.get("NRV_HOST_THREADS", "1") != "0"
     stats["host_stage"] = "native, threads" if native_threads else ("python, processes" if hostlib.load() is None else "native, processes")
     old_switch = None
     if nworkers > 1 and len(files) >= 4 and native_threads:
