@@ -104,10 +104,12 @@ int nrv_predict_device(nrv_handle* h, const float* d_signal, const float* d_read
 int nrv_predict_read_device(nrv_handle* h, const float* d_sig_ev, const float* d_feat_ev,
                             int64_t N, float* d_p1, float* d_p2, int8_t* d_a1, int8_t* d_a2);
 
-/* Windows per internal launch group (Keras' predict(batch_size=...)); default 4096.  Results do not
- * depend on the grouping.  Groups of <= 2048 windows (whole row tiles: batch % 32 == 0) run concurrently on
- * several streams, each with its own activation buffers, joined on the handle's stream before a call
- * returns; the host-pointer entry points then move 4096 / batch groups per upload / download. */
+/* Windows per launch group (Keras' predict(batch_size=...)); default 4096.  Results do not depend on the
+ * grouping (every window is its own row of every kernel).  A group below 4096 windows would leave most of the
+ * chip idle, so consecutive smaller groups of ONE call are coalesced into 4096-window launches (nrv_get_batch
+ * still reports what was set); values above 4096 make larger launches (measured: no gain, the workspace
+ * outgrows the Infinity Cache).  NRV_COALESCE=0 in the environment restores the uncoalesced form, in which
+ * groups of <= 2048 windows (batch % 32 == 0) run concurrently on several streams. */
 int nrv_set_batch(nrv_handle* h, int batch_windows);
 int nrv_get_batch(nrv_handle* h);
 
