@@ -13,7 +13,7 @@ for WHAT in "$@"; do
       timeout 300 python3 scripts/gpu_stamps.py > $O/stamps.json 2> $O/stamps.err; echo "stamps rc=$?"; tail -3 $O/stamps.err
       cat $O/stamps.json ;;
     variants)
-      VAR_REPS=2 timeout 600 python3 scripts/gpu_variants.py nanoreviser_amd/csrc/libnanorev_hip.so $(ls nanoreviser_amd/csrc/exp/libnanorev_hip_v_*.so 2>/dev/null) > $O/variants.log 2>&1
+      VAR_REPS=${VAR_REPS:-2} timeout 600 python3 scripts/gpu_variants.py nanoreviser_amd/csrc/libnanorev_hip.so $(ls nanoreviser_amd/csrc/exp/libnanorev_hip_v_*.so 2>/dev/null) > $O/variants.log 2>&1
       cat $O/variants.log | cut -c1-400 ;;
     tests)
       timeout 2700 python3 -m pytest tests -m gpu -q -s > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
