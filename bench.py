@@ -338,10 +338,10 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
 # The Bi-LSTM kernel of each mode as rocprofv3 names it, and the sources it is built from: `roofline.traffic` comes
 # from a COMMITTED PMC pass (profiles/*_pmc_lstm3.json), so it is only printed while that pass still describes the
 # kernel this library runs - same kernel name, same source text (sha256) - and is null, with the reason, otherwise.
-KERNEL_SIGNATURE = {"f16x2": "lstm_h2s_kernel<32, 16, 128, 2, 1, 2, 0, 8, 2, 1, true>",
+KERNEL_SIGNATURE = {"f16x2": "lstm_h2w_kernel<32, 16, 128, 0, 4>",
                     "bf16x3": "lstm_split_kernel<32, 16, 128, 2, 1, 0>",
                     "f32": "lstm_layer_kernel<32, 16, 128, 1, 1, false, 0>"}
-KERNEL_SOURCES = {"f16x2": ["nrv_lstm_f16x2s.h", "nrv_lstm_f16x2.h"], "bf16x3": ["nrv_lstm_bf16x3.h"],
+KERNEL_SOURCES = {"f16x2": ["nrv_lstm_f16x2w.h", "nrv_lstm_f16x2s.h", "nrv_lstm_f16x2.h"], "bf16x3": ["nrv_lstm_bf16x3.h"],
                   "f32": ["nrv_lstm_f32.h"]}
 
 
@@ -673,7 +673,7 @@ def measure(rv, step, sync, d, args, prime, rank0):
 
 
 KERNEL_NAME = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
-               "f16x2": "lstm_h2s_kernel<32,16,128,2,1,2> (16x16x32 f16 tiles)"}
+               "f16x2": "lstm_h2w_kernel<32,16,128> (16x16x32 f16 tiles, eight waves in two groups)"}
 
 
 def roofline_blocks(args, T, B, precision, m, suffix=""):

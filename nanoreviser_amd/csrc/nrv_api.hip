@@ -548,7 +548,11 @@ namespace {
     }                                                                                    \
   } while (0)
 
-static const int kUhS[4] = {0, 1, 2, 1};      // unit halves per wave of lstm_h2s_kernel for lstm2..4
+// 192 -> 128 layer: NRV_L3_WS = 1: lstm_h2w_kernel (eight waves, one unit group of 16 each, nrv_lstm_f16x2w.h); 0: lstm_h2s_kernel
+#ifndef NRV_L3_WS
+#define NRV_L3_WS 1
+#endif
+static const int kUhS[4] = {0, 1, NRV_L3_WS ? 1 : 2, 1};      // unit halves per wave of the f16x2 kernels of lstm2..4
 
 NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
   const int T = h->T;
@@ -965,6 +969,25 @@ static void launch_lstm_h2s(nrv_handle* h, int layer, const ActView (&in0)[2], c
   NRV_ACT1(else hipLaunchKernelGGL((lstm_h2s_kernel<KQ0, KQ1, H, R, WR, UH, 1, NBG, NA, KBL, RAW>), grid, blk, 0, h->stream, sa);)
 }
 
+#ifndef NRV_L3_WS_NBG
+#define NRV_L3_WS_NBG 4                              // weight ring: 4 entries (8: 36 B of scratch and 2 % slower, r04w)
+#endif
+template <int KQ0, int KQ1, int H>
+static void launch_lstm_h2w(nrv_handle* h, int layer, const ActView (&in0)[2], const ActView (&in1)[2],
+                            float* const out[2], int T, int n, int tiles) {
+  LstmH2Args sa;
+  sa.T = T; sa.n_rows = n;
+  for (int m = 0; m < 2; ++m) {
+    const DevModel& d = h->dm[m];
+    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2sf[layer], d.all + d.l_b2sf[layer], d.all + d.l_s2[layer], d.all + d.l_h2[layer],
+                                in0[m], in1[m], out[m], d.descale_f[layer]};
+  }
+  sa.n_blk = (tiles + 1) / 2;                        // 64 rows per workgroup
+  dim3 grid(lstm_grid(sa.n_blk)), blk(512);
+  if (h->act == 0) hipLaunchKernelGGL((lstm_h2w_kernel<KQ0, KQ1, H, 0, NRV_L3_WS_NBG>), grid, blk, 0, h->stream, sa);
+  NRV_ACT1(else hipLaunchKernelGGL((lstm_h2w_kernel<KQ0, KQ1, H, 1, NRV_L3_WS_NBG>), grid, blk, 0, h->stream, sa);)
+}
+
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
 // n + T - 1 events and the windows are formed on the device.  sat: the range-guard counter of the f16x2
 // signal branch for this group (one of h->d_sat's).
@@ -1117,7 +1140,11 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // both big layers on lstm_h2s_kernel: this one hands over h x 2^13 as it lies in LDS and the BatchNorm
       // behind it lives in the next layer's weights
       // (cell state in registers; 1 of its 10 weight k-blocks of 32 resident in LDS: 64 KB)
+#if NRV_L3_WS
+      launch_lstm_h2w<32, 16, 128>(h, 2, i0, i1, o, T, n, tiles);
+#else
       launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles);
+#endif
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);

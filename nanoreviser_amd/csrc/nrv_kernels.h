@@ -20,14 +20,16 @@
 //       cnn_r_kernel      signal branch (conv1 on the VALU -> conv2 -> dense 400->64 on the matrix pipe, in registers)
 //                         + the 6->16 Bi-LSTM (lstm1_unit) as four more waves of the same workgroups
 //       lstm2_t_kernel    32->64 Bi-LSTM, transposed products, wave-private recurrence
-//       lstm_h2s_kernel   192->128 Bi-LSTM <32,16,128,...> and 256->64 Bi-LSTM <64,0,64,...>, 16x16x32 f16 tiles
+//       lstm_h2w_kernel   192->128 Bi-LSTM, 16x16x32 f16 tiles, eight waves: two per SIMD running a step in opposite order
+//       lstm_h2s_kernel   256->64 Bi-LSTM <64,0,64,...>, 16x16x32 f16 tiles, one wave per SIMD
 //       head_h2_kernel    per-timestep MLP 128->128->32->6 + flatten, feature dense, softmax, argmax
 //     seven in the bf16x3 / f32 modes (cnn_kernel, lstm1_kernel, lstm_pair_kernel / lstm_split_kernel or
 //     lstm_layer_kernel x3, head_mlp(_split)_kernel, head_final_kernel); plus segment_kernel when reads arrive as raw
 //     samples.  Rows (windows) are independent: no inter-workgroup communication anywhere.
 //   * One Bi-LSTM layer = one launch; a wave owns a group of hidden units x 4 gates x R row tiles, so
 //     i,f,g,o of one (window, unit) sit in the same lane and the cell update is register-local; c never leaves the
-//     wave, h_t goes through a double-buffered LDS image (one barrier per step; lstm2_t_kernel: not even that)
+//     wave, h_t goes through an LDS image (lstm_h2s_kernel: double-buffered, one barrier per step; lstm_h2w_kernel:
+//     one image, two barriers; lstm2_t_kernel: wave-private, none)
 //     and is written out coalesced, the BatchNorm behind it fused or folded into the next layer's weights.
 #pragma once
 #include "nrv_common.h"        // vector types, buffer loads, activations, ActView
@@ -36,7 +38,8 @@
 #include "nrv_lstm_f32.h"      // lstm_layer_kernel, lstm_block / lstm_grid
 #include "nrv_lstm_bf16x3.h"   // lstm_split_kernel, lstm_pair_kernel
 #include "nrv_lstm_f16x2.h"    // the scaled two-term f16 split (NRV_PREC_F16X2): types, split2, LstmH2Args
-#include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (192->128 and 256->64 layers of the f16x2 mode, 16x16x32 tiles)
+#include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (256->64 layer of the f16x2 mode, 16x16x32 tiles; 192->128 with -DNRV_L3_WS=0)
+#include "nrv_lstm_f16x2w.h"   // lstm_h2w_kernel (192->128 layer: eight waves, two groups running a step in opposite order)
 #include "nrv_lstm2_t.h"       // lstm2_t_kernel (32->64 layer: transposed products, wave-private recurrence)
 #include "nrv_cnn_r.h"         // cnn_r_kernel (signal branch of the f16x2 mode: conv1 -> conv2 -> dense in registers)
 #include "nrv_head.h"          // head_mlp_kernel, head_mlp_split_kernel, head_final_kernel

@@ -41,11 +41,12 @@ def test_traffic_is_printed_only_for_the_kernel_it_was_measured_on(tmp_path):
 
 def test_kernel_signatures_are_what_the_library_launches():
     api = open(os.path.join(ROOT, "nanoreviser_amd", "csrc", "nrv_api.hip")).read()
-    # 192 -> 128 layer, f16x2: launch_lstm_h2s<KQ0, KQ1, H, R, WR, UH, NBG, NA, KBL, RAW> -> kernel <.., UH, ACT, NBG, NA, KBL, RAW>
-    m = re.search(r"launch_lstm_h2s<32, 16, 128, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), true>\(h, 2,", api)
+    # 192 -> 128 layer, f16x2: launch_lstm_h2w<KQ0, KQ1, H> -> lstm_h2w_kernel<KQ0, KQ1, H, ACT, NRV_L3_WS_NBG>
+    assert re.search(r"#define NRV_L3_WS 1\b", api), "the 192->128 layer left lstm_h2w_kernel: update bench.KERNEL_SIGNATURE"
+    m = re.search(r"launch_lstm_h2w<32, 16, 128>\(h, 2,", api)
     assert m, "the 192->128 launch of the f16x2 mode moved: update bench.KERNEL_SIGNATURE"
-    r, wr, uh, nbg, na, kbl = m.groups()
-    assert bench.KERNEL_SIGNATURE["f16x2"] == f"lstm_h2s_kernel<32, 16, 128, {r}, {wr}, {uh}, 0, {nbg}, {na}, {kbl}, true>"
+    nbg = re.search(r"#define NRV_L3_WS_NBG (\d+)", api).group(1)
+    assert bench.KERNEL_SIGNATURE["f16x2"] == f"lstm_h2w_kernel<32, 16, 128, 0, {nbg}>"
     for f in sum(bench.KERNEL_SOURCES.values(), []):
         assert os.path.exists(os.path.join(ROOT, "nanoreviser_amd", "csrc", f))
 

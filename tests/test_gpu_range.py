@@ -99,11 +99,13 @@ def test_whole_windows_in_the_conv1_overflow_band(reads, species_models, amp):
     # (amplified windows through the HUMAN weights: 5 - 8 % of them are ill-conditioned for f32 arithmetic itself - the
     # two CPU f32 restatements leave half the bar there -, so the share allowed is 10 %; the engine's own error on
     # every window, well- or ill-conditioned, is held to the same policy as everywhere else)
-    # ... and the bar is the amplified-input bar of test_amplified_signal_vs_fp64_oracle (2e-4): what is returned here IS the
-    # f32 mode's result (asserted above), and plain f32 matrix arithmetic sits 1.4e-4 from fp64 on one of these windows
-    # at 40x (r04g) - the guard's job is to hand over that result, not to beat f32.
-    check_vs_fp64(got[0], got[2], q1, nf1, f"x{amp:g} m1", max_ill=0.10, bar=2e-4)
-    check_vs_fp64(got[1], got[3], q2, nf2, f"x{amp:g} m2", max_ill=0.10, bar=2e-4)
+    # ... and the bar grows with the amplitude, 1e-5 per unit of amplification (2e-4 at 20x, the amplified-input bar of
+    # test_amplified_signal_vs_fp64_oracle; 6e-4 at 60x): what is returned here IS the f32 mode's result (asserted above),
+    # and plain f32 matrix arithmetic on inputs of |x| <= 500 sits 1.4e-4 from fp64 on one of these windows at 40x (r04g)
+    # and 3.9e-4 at 60x (r04y) - the guard's job is to hand over that result, not to beat f32.
+    bar = 1e-5 * amp
+    check_vs_fp64(got[0], got[2], q1, nf1, f"x{amp:g} m1", max_ill=0.10, bar=bar)
+    check_vs_fp64(got[1], got[3], q2, nf2, f"x{amp:g} m2", max_ill=0.10, bar=bar)
 
 
 @pytest.mark.parametrize("mode", MODES)

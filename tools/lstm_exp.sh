@@ -3,7 +3,8 @@
 # loaded with NRV_LIB=... / Reviser(lib_path=...); scripts/gpu_variants.py times several in one process).
 # Always the product's kernels and flags plus:
 #   tools/lstm_exp.sh stamp                      -> exp/libnanorev_hip_stamp.so   -DNRV_STAMP=1: s_memtime stamps at the phase
-#                                                   edges of lstm_h2s_kernel (scripts/gpu_stamps.py)
+#                                                   edges of lstm_h2s_kernel (scripts/gpu_stamps.py) and lstm_h2w_kernel
+#                                                   (scripts/gpu_stamps_w.py)
 #   tools/lstm_exp.sh D:name:-DNRV_X=1,-DNRV_Y=2 -> exp/libnanorev_hip_name.so    any -D flags (e.g. -DNRV_EXP=<bits>: parts of
 #                                                   cnn_r_kernel compiled out, results WRONG, timing only)
 # FAST=1 adds -DNRV_DEV_FAST (f16x2 mode with hard_sigmoid only: half the compile time; never the product).

@@ -15,7 +15,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"lstm_(?:layer|split|pair|h2o?|h2s)_kernel<(\d+), (\d+), (\d+)", name)
+    m = re.search(r"lstm_(?:layer|split|pair|h2o?|h2s|h2w)_kernel<(\d+), (\d+), (\d+)", name)
     if m:
         return {"0, 0, 16": "lstm1", "8, 0, 64": "lstm2", "32, 16, 128": "lstm3", "64, 0, 64": "lstm4"}.get(
             ", ".join(m.groups()), name)
