@@ -14,31 +14,45 @@ namespace nrv {
 // leaves 3.3 k cycles of issue idle.  A single in-order wave cannot move the one into the other.
 //
 // Here a wave owns 16 units x 4 gates x the same 64 rows (64 accumulators; a weight entry still feeds 4 row tiles x 3 products),
-// eight waves make the workgroup, and the two waves that share a SIMD (w and w + 4) run the second half of a step in OPPOSITE
-// order:
-//     all waves:            copy-out of h_{s-1}; x_{s+1} -> LDS; rec(s)
-//     barrier 1 (nobody reads h_{s-1} any more; x_{s+1} is staged)
-//     waves 0-3 (group A):  gates(s)            in(s+1) -> Z
-//     waves 4-7 (group B):  Z -> LDS, in(s+1)   gates(s) from LDS
-//     barrier 2 (h_s complete: every wave's rec(s+1) needs all of it; nobody reads x_{s+1} any more)
-// so that while one wave of a SIMD turns its accumulators into (c, h) on the vector pipe the other one feeds the matrix pipe
-// with the input projection - which depends on no h - and vice versa; their recurrent phases share the pipe.  No gate piece
-// rides between products any more (no hand-cut stages, no ticks): each wave's stream is plain, the SIMD's arbiter does the
-// interleaving.  Group B's in(s+1) needs Z's accumulators while its gates(s) still need Z's values: the 16 tiles are parked in
-// LDS (one 16-byte store per tile, issued in front of the first product that overwrites it; read back four tiles per row tile
-// by the gate code), so both groups live on 64 accumulators and fit the 256 registers of a two-wave SIMD.
+// eight waves make the workgroup, and the two waves that share a SIMD (w and w + 4) run a step in DIFFERENT order:
+//     waves 0-3 (group A):  rec(s)  [requests for x_{s+3}] gates(s) in registers | barrier 1 | h_s -> image, in(s+1) -> Z        |
+//     waves 4-7 (group B):  rec(s), Z -> LDS                                     | barrier 1 | in(s+1) -> Z, [requests for      | barrier 2
+//                                                                                |           | x_{s+2}] gates(s) from LDS -> h_s |
+//     barrier 1: nobody reads h_{s-1} any more, x_{s+1} is staged;  barrier 2: h_s complete, nobody reads x_{s+1} any more
+// so that while one wave of a SIMD turns its accumulators into (c, h) on the vector pipe the other one feeds the matrix pipe.
+// Group A - the older waves, which the SIMD's arbiter prefers when both have a product ready - is through rec(s) first and
+// does its gate arithmetic while group B still multiplies (only the 32 two-byte stores of h_s wait for barrier 1); group B's
+// input projection runs at raised priority, in front of group A's, and its gates hide behind the rest of that.  No gate piece
+// rides between products any more (no hand-cut stages, no ticks): each wave's stream is plain, the arbiter interleaves.
+// Group B's in(s+1) needs Z's accumulators while its gates(s) still need Z's values: the 16 tiles are parked in LDS (one
+// 16-byte store per tile, behind products of the last recurrent block as the tiles become final; read back four tiles per
+// row tile by the gate code), so both groups live on 64 accumulators and fit the 256 registers of a two-wave SIMD.
 //
 // The activation fragments of x_{s+1} are the same for all eight waves, and with 16 units per wave each would feed only 12
 // products: fetched per wave they double the fragment-shaped requests at the CU's vector-memory front end, which the weight
 // stream (80 KB per wave and step) already loads to two thirds (measured: 186 us against lstm_h2s_kernel's 163 on one box with
-// per-wave x loads).  So x_{s+1} goes through LDS once per workgroup: wave w fetches the fragments (row tile w / 2, term w % 2)
-// of all six k blocks during rec(s) and writes them lane-linear; in(s+1) reads them with ds_read_b128.  Barrier 1 in the
-// middle of the step makes that legal and lets h live in ONE image (gates(s) overwrite h_{s-1} behind it): 33 KB (h) + 64 KB
-// (group B's tiles) + 48 KB (x) = 145 KB of LDS.
+// per-wave x loads).  So x goes through LDS once per workgroup: wave w fetches the fragments (row tile w / 2, term w % 2)
+// of all six k blocks - requested at the start of its gate arithmetic, the one stretch in which it waits for no weight entry
+// (the memory counter is in order) - and writes them lane-linear behind products of the next rec(); in() reads them with
+// ds_read_b128.  Barrier 1 in the middle of the step makes that legal and lets h live in ONE image (gates(s) overwrite
+// h_{s-1} behind it): 33 KB (h) + 64 KB (group B's tiles) + 48 KB (x) = 145 KB of LDS.
+//
+// Every request is issued BEHIND a product inside a chain of three (tools/microbench/tick_cost.hip: two 1 KB requests in front
+// of an entry's 12 products cost 2.3 cycles per product, inside a chain 0.6).
+//
+// In-kernel stamps (scripts/gpu_stamps_w.py; profiles/r04*_stamps_lstm_h2w.json): 19.3 k cycles per step against
+// lstm_h2s_kernel's 23.6 k and 15.5 k of matrix pipe; the second half runs pipe-bound, the first at 80 % (group B's rec()
+// gets 23 % of the pipe while group A's runs, then shares the SIMD with group A's gate arithmetic).
 //
 // Everything else is lstm_h2s_kernel's: operand layouts, the split h image, the scales, the packed weights
 // (pack_lstm_h2s with one unit half per wave), the raw copy-out of h x 2^13.
 // ---------------------------------------------------------------------------------------
+#ifndef NRV_STAMP_REC_ENTRIES
+#define NRV_STAMP_REC_ENTRIES 0
+#endif
+#ifndef NRV_WS_DEFER
+#define NRV_WS_DEFER 1
+#endif
 #if NRV_STAMP
 // diagnostic build: [wave 8][step 15][slot 16] s_memtime stamps per workgroup, in the stamp buffer's region of this layer
 #define NRV_STAMP_W(slot)                                                                                    \
@@ -145,25 +159,25 @@ lstm_h2w_kernel(const LstmH2Args args) {
     }
     return sb;
   };
-  f32x4 xs[KK_IN / 2];                                         // staging: half of the k blocks at a time
-  constexpr int XH = KK_IN / 2;
+  f32x4 xs[KK_IN];
   auto stage_load1 = [&](const SBase& sb, int kk) __attribute__((always_inline)) {
-    xs[kk % XH] = (KQ1 == 0 || kk < KK0) ? buf_load16(sb.r0, sb.v0, kk * 4096) : buf_load16(sb.r1, sb.v1, (kk - KK0) * 4096);
+    xs[kk] = (KQ1 == 0 || kk < KK0) ? buf_load16(sb.r0, sb.v0, kk * 4096) : buf_load16(sb.r1, sb.v1, (kk - KK0) * 4096);
   };
-  auto stage_store1 = [&](int half, int i) __attribute__((always_inline)) {
-    *(f32x4*)(xw + (half * XH + i) * RT * 2 * XF) = xs[i];
-  };
-  auto stage_store = [&](int half) __attribute__((always_inline)) {
+  // The six requests of a wave's share go out TOGETHER at the start of its gate arithmetic - the one stretch of a step in
+  // which the wave waits for no weight entry: the memory counter is in order, so a request to HBM in front of a weight
+  // request holds the products behind that entry back until it has landed (with the requests riding on rec() entries, rec()
+  // ran at 21 cycles per product with both waves of a SIMD in it - stamps, r04aa).
+  auto stage_load = [&](const SBase& sb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < XH; ++i) *(f32x4*)(xw + (half * XH + i) * RT * 2 * XF) = xs[i];
+    for (int kk = 0; kk < KK_IN; ++kk) stage_load1(sb, kk);
+  };
+  auto stage_store1 = [&](int kk) __attribute__((always_inline)) {
+    *(f32x4*)(xw + kk * RT * 2 * XF) = xs[kk];
   };
   auto stage_all = [&](const SBase& sb) __attribute__((always_inline)) {      // prologue only: nothing to hide behind
+    stage_load(sb);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int i = 0; i < XH; ++i) stage_load1(sb, half * XH + i);
-      stage_store(half);
-    }
+    for (int kk = 0; kk < KK_IN; ++kk) stage_store1(kk);
   };
 
   struct BReg { f16x8 t[2]; };
@@ -216,7 +230,9 @@ lstm_h2w_kernel(const LstmH2Args args) {
     for (int rt = 0; rt < RT; ++rt) loadA_in(0, rt, a[rt]);
 #pragma unroll
     for (int kk = 0; kk < KK_IN; ++kk) {
+#if !NRV_STAMP_REC_ENTRIES
       if (!FIRST && kk > 0) NRV_STAMP_D(kk - 1);
+#endif
 #pragma unroll
       for (int g = 0; g < EPK; ++g) {
         const int e = EPK * kk + g;
@@ -258,15 +274,21 @@ lstm_h2w_kernel(const LstmH2Args args) {
     chi[i] = *(const f16x8*)(himg + kbh * GS + rr * 8);
     clo[i] = *(const f16x8*)(himg + kbh * GS + rr * 8 + TERM);
   };
-  auto copy_write1 = [&](int i, int term, int t) __attribute__((always_inline)) {
+  // (stores through a descriptor on this workgroup's first output tile: the step enters as a scalar offset, the item's
+  // place is a per-lane constant - no 64-bit address arithmetic between the products)
+  const __amdgpu_buffer_rsrc_t ors = make_rsrc(P.out + (size_t)(blk.rowblk * R) * T * (2 * H / 4) * 128, 0xffffffffu);
+  unsigned cw_off[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
     constexpr int KBH = H / 16;
-    if (term < 0 || term > 1) return;
     const int it = threadIdx.x + i * NTHREADS;
     const int kbh = it / ROWS, rr = it % ROWS;
-    const int tile = blk.rowblk * R + rr / 32;
-    float* dst = P.out + ((size_t)(tile * T + t) * (2 * H / 4) + (dir * KBH + (kbh >> 1)) * 4 + (kbh & 1)) * 128 + (rr & 31) * 4;
-    if (term == 0) *(f16x8*)dst = chi[i];
-    else *(f16x8*)(dst + 2 * 128) = clo[i];
+    cw_off[i] = (unsigned)((((rr / 32) * T * (2 * H / 4) + (dir * KBH + (kbh >> 1)) * 4 + (kbh & 1)) * 128 + (rr & 31) * 4) * 4);
+  }
+  auto copy_write1 = [&](int i, int term, int t) __attribute__((always_inline)) {
+    if (term < 0 || term > 1) return;
+    const unsigned soff = (unsigned)t * ((2 * H / 4) * 128 * 4) + term * (2 * 128 * 4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, term == 0 ? chi[i] : clo[i]), ors, cw_off[i], soff, 0);
   };
   auto copy_write = [&](int i, int t) __attribute__((always_inline)) {
     copy_write1(i, 0, t);
@@ -279,25 +301,29 @@ lstm_h2w_kernel(const LstmH2Args args) {
     for (int i = 0; i < NIT; ++i) copy_write(i, t);
   };
   // ---- rec(): Z += h U, h from the image behind barrier 2.  The step's other memory work rides on its entries (all eight
-  // waves enter together: issued in one burst these requests held the phase's first products back by 1.3-3.7 k cycles -
-  // in-kernel stamps, r04q): the six staging requests of the next x, the copy-out of h_{s-1}, the staged fragments' way
-  // into LDS.  STASH (group B): in the last block the tiles of an entry are final when it is through, and are parked in
+  // waves enter together: issued in one burst these pieces held the phase's first products back by 1.3-3.7 k cycles -
+  // in-kernel stamps, r04q): the staged fragments' way into LDS and the copy-out of h_{s-1}.  STASH (group B): in the last block the tiles of an entry are final when it is through, and are parked in
   // LDS behind products of the next one.
-  auto rec_phase = [&](auto stash_tag, f32x4 (&Z)[4][RT], const SBase& sb, int t_out) __attribute__((always_inline)) {
+  auto rec_phase = [&](auto stash_tag, f32x4 (&Z)[4][RT], int t_out) __attribute__((always_inline)) {
     constexpr bool STASH = decltype(stash_tag)::value;
-    // side work by entry, behind product 10 (and 9, 11): 0..2 staging requests (first half) | 3, 5 copy-out reads |
-    // 4, 6 copy-out stores | 7 first half -> LDS | 8..10 staging requests (second half) | 14 second half -> LDS
-    static_assert(XH == 3 && NIT == 2 && EPK * KK_REC == 16, "the side-work table below");
+    // side work by entry, behind product 10 (and 11): 0..5 the staged fragments (requested during the gates before) -> LDS |
+    // 6, 8 copy-out reads | 7, 9 copy-out stores
+    static_assert(KK_IN == 6 && NIT == 2 && EPK * KK_REC == 16, "the side-work table below");
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) loadA_rec(0, rt, a[rt]);
 #pragma unroll
     for (int kr = 0; kr < KK_REC; ++kr) {
       const int kk = KK_IN + kr;
+#if !NRV_STAMP_REC_ENTRIES
       if (kr > 0) NRV_STAMP_D(4 + kr);
+#endif
 #pragma unroll
       for (int g = 0; g < EPK; ++g) {
         const int e = EPK * kk + g, er = EPK * kr + g;
         const int en = (e + LBG) % (EPK * KK);
+#if NRV_STAMP_REC_ENTRIES
+        if (er >= 1 && er <= 8) NRV_STAMP_D(er - 1);           // one-off: the first eight entries of rec(), slots 7..14
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 3 * RT; ++m) {
@@ -307,7 +333,7 @@ lstm_h2w_kernel(const LstmH2Args args) {
           frag_piece(g, m, rn, tn);
           const bool frag = rn >= 0 && kr + 1 < KK_REC;
           const bool stash = STASH && kr == KK_REC - 1 && g > 0 && (m == 4 || m == 5 || m == 7 || m == 8);
-          const bool side = m >= 9;
+          const bool side = m >= 10 && er < 10;
           if (m < 2 || frag || stash || side) {
             __builtin_amdgcn_sched_barrier(0);
             if (m < 2) loadB1(en, m, b[(e + LBG) % NBG]);
@@ -317,15 +343,12 @@ lstm_h2w_kernel(const LstmH2Args args) {
               *(f32x4*)(zw + ((g - 1) * RT + rs) * 256) = Z[g - 1][rs];
             }
             if (m == 10) {
-              if (er < 3) stage_load1(sb, er);
-              if (er == 3) copy_read(0);
-              if (er == 5) copy_read(1);
-              if (er >= 8 && er < 11) stage_load1(sb, er - 5);
+              if (er < KK_IN) stage_store1(er);
+              if (er == 6) copy_read(0);
+              if (er == 8) copy_read(1);
             }
-            if (er == 4) copy_write1(0, m - 10, t_out);       // m = 10, 11: the two term planes
-            if (er == 6) copy_write1(1, m - 10, t_out);
-            if (er == 7 && m >= 9) stage_store1(0, m - 9);    // m = 9, 10, 11: three fragments
-            if (er == 14 && m >= 9) stage_store1(1, m - 9);
+            if (er == 7) copy_write1(0, m - 10, t_out);       // m = 10, 11: the two term planes
+            if (er == 9) copy_write1(1, m - 10, t_out);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -334,8 +357,10 @@ lstm_h2w_kernel(const LstmH2Args args) {
     __builtin_amdgcn_sched_barrier(0);
   };
   // ---- gates of step s from Z: c, h -> the split image of h_s (plain: the SIMD's other wave owns the matrix pipe meanwhile)
-  auto gates = [&](auto lds_tag, const f32x4 (&Z)[4][RT]) __attribute__((always_inline)) {
-    constexpr bool FROM_LDS = decltype(lds_tag)::value;
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  f16x2 hpk[NE];                                         // DEFER: (hi, lo) of the element's h, written by gates_write()
+  auto gates = [&](auto lds_tag, auto defer_tag, const f32x4 (&Z)[4][RT]) __attribute__((always_inline)) {
+    constexpr bool FROM_LDS = decltype(lds_tag)::value, DEFER = decltype(defer_tag)::value;
     f32x4 zt[2][4];                                      // FROM_LDS: the four gate tiles of a row tile, one row tile ahead
     if constexpr (FROM_LDS) {
 #pragma unroll
@@ -372,9 +397,21 @@ lstm_h2w_kernel(const LstmH2Args args) {
       const float hv = zo * __builtin_fmaf(t, -2.0f * kHScale, kHScale);        // og * tanh(c) * 2^13
       const _Float16 hh = (_Float16)hv;
       const _Float16 hl = (_Float16)(hv - (float)hh);
-      hw[(rt * 16 + reg) * 8] = hh;
-      hw[(rt * 16 + reg) * 8 + TERM] = hl;
+      if constexpr (DEFER) {
+        hpk[e] = f16x2{hh, hl};
+      } else {
+        hw[(rt * 16 + reg) * 8] = hh;
+        hw[(rt * 16 + reg) * 8 + TERM] = hl;
+      }
       if (reg == 3) __builtin_amdgcn_sched_barrier(0);   // four elements in flight are enough: the other wave fills the gaps
+    }
+  };
+  auto gates_write = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int rt = e / 4, reg = e % 4;
+      hw[(rt * 16 + reg) * 8] = hpk[e][0];
+      hw[(rt * 16 + reg) * 8 + TERM] = hpk[e][1];
     }
   };
   f32x4 Z[4][RT];
@@ -385,19 +422,30 @@ lstm_h2w_kernel(const LstmH2Args args) {
   auto run = [&](auto a_tag) __attribute__((always_inline)) {
     constexpr bool GRP_A = decltype(a_tag)::value;
     auto s_clamp = [&](int s) __attribute__((always_inline)) { return s < T ? s : T - 1; };   // past the end: staged again, read by nobody
+    // Group A's gate arithmetic of a step follows its rec() at once, in FRONT of barrier 1 - group A (the older waves, which
+    // the SIMD's arbiter prefers) is through rec() 2.8 k cycles before group B (stamps, r04y) and would wait there; only the
+    // 32 two-byte stores of h_s have to stay behind the barrier (other waves still read h_{s-1}).
+    constexpr bool DEFER = GRP_A && NRV_WS_DEFER;
+    typedef std::integral_constant<bool, DEFER> defer_t;
     {
       stage_all(mk_stage(0));
 #pragma unroll
       for (int e = 0; e < LBG; ++e) loadB(e % (EPK * KK_IN), b[e]);
       __syncthreads();                                   // x_0 staged, the image of h_{-1} zeroed
+      stage_load(mk_stage(s_clamp(1)));                  // (x_1's requests fly during in(0))
       in_phase(std::true_type{}, std::false_type{}, Z);
       __syncthreads();                                   // nobody reads x_0 any more
-      stage_all(mk_stage(s_clamp(1)));
+#pragma unroll
+      for (int kk = 0; kk < KK_IN; ++kk) stage_store1(kk);
       if constexpr (!GRP_A) {                            // step 0 has no rec() to park group B's tiles
 #pragma unroll
         for (int g = 0; g + 1 < EPK; ++g)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) *(f32x4*)(zw + (g * RT + rt) * 256) = Z[g][rt];
+      }
+      if constexpr (DEFER) {
+        stage_load(mk_stage(s_clamp(2)));
+        gates(std::false_type{}, defer_t{}, Z);
       }
       __syncthreads();                                   // barrier 1 of step 0 (which has no rec)
     }
@@ -409,25 +457,37 @@ lstm_h2w_kernel(const LstmH2Args args) {
 #endif
       NRV_STAMP_W(0);
       if constexpr (GRP_A) {
-        gates(std::false_type{}, Z);
+        if constexpr (DEFER) {
+          gates_write();
+        } else {
+          stage_load(mk_stage(s_clamp(s + 2)));
+          gates(std::false_type{}, std::false_type{}, Z);
+        }
         NRV_STAMP_W(1);
         in_phase(std::false_type{}, std::false_type{}, Z);
       } else {
         in_phase(std::false_type{}, std::true_type{}, Z);
         NRV_STAMP_W(1);
-        gates(std::true_type{}, Z);
+        stage_load(mk_stage(s_clamp(s + 2)));
+        gates(std::true_type{}, std::false_type{}, Z);
       }
       NRV_STAMP_W(2);
       __syncthreads();                                   // barrier 2: h_s complete, Z = x_{s+1} W
       NRV_STAMP_W(3);
       NRV_STAMP_W(4);
-      rec_phase(std::integral_constant<bool, !GRP_A>{}, Z, mk_stage(s_clamp(s + 2)), t_of(s));
+      rec_phase(std::integral_constant<bool, !GRP_A>{}, Z, t_of(s));     // (the fragments of x_{s+2} go to LDS in here)
       NRV_STAMP_W(5);
+      if constexpr (DEFER) {
+        stage_load(mk_stage(s_clamp(s + 3)));
+        gates(std::false_type{}, defer_t{}, Z);
+      }
+      NRV_STAMP_D(8);
       __syncthreads();                                   // barrier 1 of step s + 1
       NRV_STAMP_W(6);
       NRV_STAMP_FLUSH();
     }
-    gates(std::false_type{}, Z);                         // the last step: nothing follows its gates
+    if constexpr (DEFER) gates_write();                  // the last step: nothing follows its gates
+    else gates(std::false_type{}, std::false_type{}, Z);
     __syncthreads();
     copy_out(t_of(T - 1));
 #if NRV_STAMP

@@ -4,7 +4,8 @@ diagnostic build (-DNRV_STAMP=1 -DNRV_L3_WS=1) after a few hundred bench steps o
   python3 scripts/gpu_stamps_w.py lib.so > gpurun_out/stamps_w.json
 Slots per (workgroup, wave, loop iteration): 0 top (second half of step s) | 1 A: gates done, B: in() done |
 2 second half done | 3 behind barrier 2 | 4 rec() starts | 5 rec() done | 6 behind barrier 1 | 7..11 in() k blocks 1..5 start |
-12..14 rec() k blocks 1..3 start (7..14: s_memtime not waited for until the end of the iteration).
+12..14 rec() k blocks 1..3 start | 15 arrival at barrier 1 (7..15: s_memtime not waited for until the end of the
+iteration).
 Step row 14: s_memrealtime at kernel start / end.  Read SHARES, not lengths (the stamps' fences forbid some overlap)."""
 import ctypes as C
 import json
@@ -64,7 +65,8 @@ for name, ws in (("group_A", slice(0, 4)), ("group_B", slice(4, 8))):
         "wait_barrier2": med(g[..., 3] - g[..., 2]),
         "copy_out_and_requests": med(g[..., 4] - g[..., 3]),
         "rec": med(g[..., 5] - g[..., 4]),
-        "wait_barrier1": med(g[..., 6] - g[..., 5]),
+        "gates_in_front_of_barrier1 (A, deferred)": med(g[..., 15] - g[..., 5]),
+        "wait_barrier1": med(g[..., 6] - g[..., 15]),
     }
     in0 = g[..., 0] if name == "group_B" else g[..., 1]          # in() starts at the top (B) or behind the gates (A)
     in_end = g[..., 1] if name == "group_B" else g[..., 2]
@@ -74,5 +76,10 @@ for name, ws in (("group_A", slice(0, 4)), ("group_B", slice(4, 8))):
     out[name]["rec_blocks"] = [med(r[k + 1] - r[k]) for k in range(4)]
     out[name]["deferred_stamps_monotonic"] = bool(all((e[k + 1] >= e[k]).all() for k in range(6)) and
                                                   all((r[k + 1] >= r[k]).all() for k in range(4)))
+if os.environ.get("STAMP_REC_ENTRIES") == "1":             # one-off build -DNRV_STAMP_REC_ENTRIES=1: slots 7..14 = entries 1..8 of rec()
+    for name, ws in (("group_A", slice(0, 4)), ("group_B", slice(4, 8))):
+        g = s[:, ws, it, :]
+        e = [g[..., 4]] + [g[..., 7 + k] for k in range(8)]
+        out[name]["rec_entries_0_7"] = [med(e[k + 1] - e[k]) for k in range(8)]
 json.dump(out, sys.stdout, indent=1)
 print()
