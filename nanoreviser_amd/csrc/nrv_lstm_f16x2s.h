@@ -35,6 +35,9 @@ namespace nrv {
 #ifndef NRV_STAMP
 #define NRV_STAMP 0
 #endif
+#ifndef NRV_H2S_INCHAIN
+#define NRV_H2S_INCHAIN 2
+#endif
 #if NRV_STAMP
 constexpr int kStampSlots = 32, kStampSteps = 15, kStampWaves = 4, kStampBlocks = 256;
 __device__ unsigned long long nrv_stamp_buf[2][kStampBlocks][kStampWaves][kStampSteps][kStampSlots];
@@ -199,6 +202,23 @@ lstm_h2s_kernel(const LstmH2Args args) {
     d.v[1] = *(const f32x4*)(qh + TERM);                 // lo first, as for x
     d.v[0] = *(const f32x4*)(qh);
   };
+  // NRV_H2S_INCHAIN: one request at a time, issued BEHIND a product inside a chain of three instead of in front of the
+  // entry / block (tools/microbench/tick_cost.hip: two 1 KB requests in front of an entry's 12 products cost 2.3 cycles
+  // per product, inside a chain 0.6; lstm_h2w_kernel is built that way)
+  auto loadB1 = [&](int e, int term, BReg& bb) __attribute__((always_inline)) {
+    if (KBL > 0 && e < KBL * EPK) bb.t[term] = __builtin_bit_cast(f16x8, *(const f32x4*)(wlw + (e * 2 + term) * 256));
+    else bb.t[term] = __builtin_bit_cast(f16x8, buf_load16(wrs, wlane, (e * 2 + term) * 1024));
+  };
+  auto loadA_in1 = [&](const ABase& ab, int kk, int rt, int term, AReg& d) __attribute__((always_inline)) {
+    const int r = rt >> 1, sub = rt & 1;
+    if (KQ1 == 0 || kk < KK0) d.v[term] = buf_load16(ab.r0[r], ab.v0[r][sub], kk * 4096 + term * 1024);
+    else d.v[term] = buf_load16(ab.r1[r], ab.v1[r][sub], (kk - KK0) * 4096 + term * 1024);
+  };
+  auto loadA_rec1 = [&](const _Float16* hp, int kkr, int rt, int term, AReg& d) __attribute__((always_inline)) {
+    d.v[term] = *(const f32x4*)(hp + kkr * 4 * GS + rt * 128 + term * TERM);
+  };
+  constexpr int APPE = (2 * RT + EPK - 1) / EPK;             // fragment pieces (row tile, term) per entry, behind products 4..
+  static_assert(4 + APPE <= 3 * RT, "fragment pieces must fit behind an entry's products");
   // hi*lo, lo*hi, hi*hi: the first product of an entry takes the LAST-requested fragment of both operands
   constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 
@@ -314,8 +334,9 @@ lstm_h2s_kernel(const LstmH2Args args) {
 #pragma unroll
     for (int kk = 0; kk < KK_IN; ++kk) {
       if constexpr (WORK) NRV_STAMP_AT(8 + kk);
+      const int ka = kk + LA;                            // activations LA blocks ahead: input, then recurrent
+#if NRV_H2S_INCHAIN != 1
       {
-        const int ka = kk + LA;                          // activations LA blocks ahead: input, then recurrent
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           if (ka < KK_IN) loadA_in(xb, ka, rt, a[ka % NA][rt]);
@@ -323,10 +344,14 @@ lstm_h2s_kernel(const LstmH2Args args) {
           else loadA_in(xb_wrap, ka - KK_IN, rt, a[ka % NA][rt]);
         }
       }
+#endif
 #pragma unroll
       for (int ge = 0; ge < EPK; ++ge) {
         const int e = EPK * kk + ge, g = ge / UH, uh = ge % UH;
-        loadB(WORK ? (e + LBG) % (EPK * KK) : (e + LBG) % (EPK * KK_IN), b[(e + LBG) % NBG]);
+        const int en = WORK ? (e + LBG) % (EPK * KK) : (e + LBG) % (EPK * KK_IN);
+#if NRV_H2S_INCHAIN != 1
+        loadB(en, b[(e + LBG) % NBG]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -335,6 +360,23 @@ lstm_h2s_kernel(const LstmH2Args args) {
             const int tk = (e * RT + rt) * 3 + pr;
             N[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]],
                                       (kk == 0 && pr == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : N[g][uh][rt]);
+#if NRV_H2S_INCHAIN == 1
+            {
+              const int m = rt * 3 + pr, pa = ge * APPE + (m - 4);
+              const bool fa = m >= 4 && m < 4 + APPE && pa < 2 * RT;
+              if (m < 2 || fa) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 2) loadB1(en, m, b[(e + LBG) % NBG]);
+                if (fa) {
+                  const int rn = pa / 2, tn = pa % 2;
+                  if (ka < KK_IN) loadA_in1(xb, ka, rn, tn, a[ka % NA][rn]);
+                  else if (WORK) loadA_rec1(hp_next, ka - KK_IN, rn, tn, a[ka % NA][rn]);
+                  else loadA_in1(xb_wrap, ka - KK_IN, rn, tn, a[ka % NA][rn]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#endif
             if constexpr (WORK) {
               if (tk < TG) {
 #pragma unroll
@@ -364,24 +406,44 @@ lstm_h2s_kernel(const LstmH2Args args) {
     for (int kr = 0; kr < KK_REC; ++kr) {
       const int kk = KK_IN + kr;
       NRV_STAMP_AT(1 + kr);
+      const int ka = kk + LA;
+#if !NRV_H2S_INCHAIN
       {
-        const int ka = kk + LA;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           if (ka < KK) loadA_rec(hp, ka - KK_IN, rt, a[ka % NA][rt]);
           else loadA_in(xb_next, ka - KK, rt, a[ka % NA][rt]);
         }
       }
+#endif
 #pragma unroll
       for (int ge = 0; ge < EPK; ++ge) {
         const int e = EPK * kk + ge, g = ge / UH, uh = ge % UH;
-        loadB((e + LBG) % (EPK * KK), b[(e + LBG) % NBG]);
+        const int en = (e + LBG) % (EPK * KK);
+#if !NRV_H2S_INCHAIN
+        loadB(en, b[(e + LBG) % NBG]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int pr = 0; pr < 3; ++pr)
+          for (int pr = 0; pr < 3; ++pr) {
             Z[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]], Z[g][uh][rt]);
+#if NRV_H2S_INCHAIN
+            const int m = rt * 3 + pr, pa = ge * APPE + (m - 4);
+            const bool fa = m >= 4 && m < 4 + APPE && pa < 2 * RT;
+            if (m < 2 || fa) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (m < 2) loadB1(en, m, b[(e + LBG) % NBG]);
+              if (fa) {
+                const int rn = pa / 2, tn = pa % 2;
+                if (ka < KK) loadA_rec1(hp, ka - KK_IN, rn, tn, a[ka % NA][rn]);
+                else loadA_in1(xb_next, ka - KK, rn, tn, a[ka % NA][rn]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
