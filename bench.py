@@ -346,11 +346,17 @@ KERNEL_SOURCES = {"f16x2": ["nrv_lstm_f16x2w.h", "nrv_lstm_f16x2s.h", "nrv_lstm_
 
 
 def kernel_source_sha(precision):
+    """sha256 of the kernel's sources as the compiler sees them: `//` comments and blank lines do not count (a comment
+    edit must not orphan a PMC pass; none of these files has `//` inside a string or a block comment)."""
     import hashlib
+    import re
     hsh = hashlib.sha256()
     for f in KERNEL_SOURCES[precision]:
-        with open(os.path.join(ROOT, "nanoreviser_amd", "csrc", f), "rb") as fp:
-            hsh.update(fp.read())
+        with open(os.path.join(ROOT, "nanoreviser_amd", "csrc", f), "r") as fp:
+            for line in fp:
+                code = re.sub(r"\s*//.*$", "", line.rstrip("\n")).rstrip()
+                if code:
+                    hsh.update(code.encode() + b"\n")
     return hsh.hexdigest()[:16]
 
 

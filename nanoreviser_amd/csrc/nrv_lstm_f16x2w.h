@@ -40,6 +40,10 @@ namespace nrv {
 // Every request is issued BEHIND a product inside a chain of three (tools/microbench/tick_cost.hip: two 1 KB requests in front
 // of an entry's 12 products cost 2.3 cycles per product, inside a chain 0.6).
 //
+// Registers: 256 per wave (two waves per SIMD), none to spare: hipcc parks five address values of the epilogue's copy-out in
+// scratch (24 B per lane) in front of the loop and fetches them back behind it; there is no scratch instruction inside the
+// loop (tools/isa_of.sh; a weight ring of 8 entries, or precomputing those addresses, puts some there).
+//
 // In-kernel stamps (scripts/gpu_stamps_w.py; profiles/r04*_stamps_lstm_h2w.json): 19.3 k cycles per step against
 // lstm_h2s_kernel's 23.6 k and 15.5 k of matrix pipe; the second half runs pipe-bound, the first at 80 % (group B's rec()
 // gets 23 % of the pipe while group A's runs, then shares the SIMD with group A's gate arithmetic).
