@@ -21,7 +21,8 @@ namespace nrv {
 //     barrier 1: nobody reads h_{s-1} any more, x_{s+1} is staged;  barrier 2: h_s complete, nobody reads x_{s+1} any more
 // so that while one wave of a SIMD turns its accumulators into (c, h) on the vector pipe the other one feeds the matrix pipe.
 // Group A - the older waves, which the SIMD's arbiter prefers when both have a product ready - is through rec(s) first and
-// does its gate arithmetic while group B still multiplies (only the 32 two-byte stores of h_s wait for barrier 1); group B's
+// does its gate arithmetic while group B still multiplies (only the 32 two-byte stores of h_s wait for barrier 1, and ride on
+// the first entries of its in(s+1): as a burst at the head of the second half they held group B's first fragment reads back); group B's
 // input projection runs at raised priority, in front of group A's, and its gates hide behind the rest of that.  No gate piece
 // rides between products any more (no hand-cut stages, no ticks): each wave's stream is plain, the arbiter interleaves.
 // Group B's in(s+1) needs Z's accumulators while its gates(s) still need Z's values: the 16 tiles are parked in LDS (one
@@ -222,11 +223,13 @@ lstm_h2w_kernel(const LstmH2Args args) {
   };
   constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};          // hi*lo, lo*hi, hi*hi
 
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  f16x2 hpk[NE];                                         // DEFER: (hi, lo) of the element's h: stored by in() / gates_write()
   // ---- in(): D = x W over the input blocks from the staged x (first product of a tile: C = 0).  FIRST: the prologue's
   // in(0), whose weight requests wrap around to in(1)'s entries (step 0 has no rec()).  STASH: group B, whose rec() parked
   // the tiles of entries 0..2 already; entry 3's follow behind products of entries 0 and 1.
-  auto in_phase = [&](auto first_tag, auto stash_tag, f32x4 (&D)[4][RT]) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value, STASH = decltype(stash_tag)::value;
+  auto in_phase = [&](auto first_tag, auto stash_tag, auto hw_tag, f32x4 (&D)[4][RT]) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value, STASH = decltype(stash_tag)::value, HWRITE = decltype(hw_tag)::value;
     // Group B's projection goes first on the SIMD (its gates still have to follow and want group A's projection to hide
     // behind); either one goes in front of the other wave's gate arithmetic, which fills the gaps.
     __builtin_amdgcn_s_setprio(STASH ? 3 : 2);
@@ -250,8 +253,10 @@ lstm_h2w_kernel(const LstmH2Args args) {
           int rn, tn;
           frag_piece(g, m, rn, tn);
           const bool stash = STASH && kk == 0 && g < 2 && (m == 7 || m == 10);
-          if (m < 2 || (rn >= 0 && kk + 1 < KK_IN) || stash) {
+          const bool hwr = HWRITE && e < NE && (m == 3 || m == 10);  // group A: element e of h_s, hi behind product 3, lo behind 10
+          if (m < 2 || (rn >= 0 && kk + 1 < KK_IN) || stash || hwr) {
             __builtin_amdgcn_sched_barrier(0);
+            if (hwr) hw[((e / 4) * 16 + e % 4) * 8 + (m == 10 ? TERM : 0)] = hpk[e][m == 10 ? 1 : 0];   // (an int index: a bool one reads element -1)
             if (m < 2) loadB1(en, m, b[(e + LBG) % NBG]);
             if (rn >= 0 && kk + 1 < KK_IN) loadA_in1(kk + 1, rn, tn, a[(4 * (kk + 1) + rn) % NAS]);
             if (stash) {
@@ -361,8 +366,6 @@ lstm_h2w_kernel(const LstmH2Args args) {
     __builtin_amdgcn_sched_barrier(0);
   };
   // ---- gates of step s from Z: c, h -> the split image of h_s (plain: the SIMD's other wave owns the matrix pipe meanwhile)
-  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-  f16x2 hpk[NE];                                         // DEFER: (hi, lo) of the element's h, written by gates_write()
   auto gates = [&](auto lds_tag, auto defer_tag, const f32x4 (&Z)[4][RT]) __attribute__((always_inline)) {
     constexpr bool FROM_LDS = decltype(lds_tag)::value, DEFER = decltype(defer_tag)::value;
     f32x4 zt[2][4];                                      // FROM_LDS: the four gate tiles of a row tile, one row tile ahead
@@ -437,7 +440,7 @@ lstm_h2w_kernel(const LstmH2Args args) {
       for (int e = 0; e < LBG; ++e) loadB(e % (EPK * KK_IN), b[e]);
       __syncthreads();                                   // x_0 staged, the image of h_{-1} zeroed
       stage_load(mk_stage(s_clamp(1)));                  // (x_1's requests fly during in(0))
-      in_phase(std::true_type{}, std::false_type{}, Z);
+      in_phase(std::true_type{}, std::false_type{}, std::false_type{}, Z);
       __syncthreads();                                   // nobody reads x_0 any more
 #pragma unroll
       for (int kk = 0; kk < KK_IN; ++kk) stage_store1(kk);
@@ -461,16 +464,14 @@ lstm_h2w_kernel(const LstmH2Args args) {
 #endif
       NRV_STAMP_W(0);
       if constexpr (GRP_A) {
-        if constexpr (DEFER) {
-          gates_write();
-        } else {
+        if constexpr (!DEFER) {
           stage_load(mk_stage(s_clamp(s + 2)));
           gates(std::false_type{}, std::false_type{}, Z);
         }
         NRV_STAMP_W(1);
-        in_phase(std::false_type{}, std::false_type{}, Z);
+        in_phase(std::false_type{}, std::false_type{}, defer_t{}, Z);   // (DEFER: the stores of h_s ride on its first entries)
       } else {
-        in_phase(std::false_type{}, std::true_type{}, Z);
+        in_phase(std::false_type{}, std::true_type{}, std::false_type{}, Z);
         NRV_STAMP_W(1);
         stage_load(mk_stage(s_clamp(s + 2)));
         gates(std::true_type{}, std::false_type{}, Z);
