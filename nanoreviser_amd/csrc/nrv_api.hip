@@ -988,31 +988,6 @@ static void launch_lstm_h2w(nrv_handle* h, int layer, const ActView (&in0)[2], c
   NRV_ACT1(else hipLaunchKernelGGL((lstm_h2w_kernel<KQ0, KQ1, H, 1, NRV_L3_WS_NBG>), grid, blk, 0, h->stream, sa);)
 }
 
-// 256 -> 64 layer: NRV_L4_K = 1: lstm_h2k_kernel (eight waves, the reduction split in two, nrv_lstm_f16x2k.h); 0: lstm_h2s_kernel
-#ifndef NRV_L4_K
-#define NRV_L4_K 0
-#endif
-#ifndef NRV_L4_NBG
-#define NRV_L4_NBG 8                                 // weight ring: a wave that runs alone needs the depth (4: 32 ticks per product)
-#endif
-#ifndef NRV_L4_KA
-#define NRV_L4_KA 4                                  // input k-blocks (of 8) that group A multiplies besides the recurrent ones
-#endif
-template <int KQ0, int H>
-static void launch_lstm_h2k(nrv_handle* h, int layer, const ActView (&in0)[2], float* const out[2], int T, int n, int tiles) {
-  LstmH2Args sa;
-  sa.T = T; sa.n_rows = n;
-  for (int m = 0; m < 2; ++m) {
-    const DevModel& d = h->dm[m];
-    sa.m[m] = LstmH2ModelParams{d.all + d.l_w2sf[layer], d.all + d.l_b2sf[layer], d.all + d.l_s2[layer], d.all + d.l_h2[layer],
-                                in0[m], ActView{}, out[m], d.descale_f[layer]};
-  }
-  sa.n_blk = (tiles + 1) / 2;                        // 64 rows per workgroup
-  dim3 grid(lstm_grid(sa.n_blk)), blk(512);
-  if (h->act == 0) hipLaunchKernelGGL((lstm_h2k_kernel<KQ0, H, 0, NRV_L4_NBG, NRV_L4_KA>), grid, blk, 0, h->stream, sa);
-  NRV_ACT1(else hipLaunchKernelGGL((lstm_h2k_kernel<KQ0, H, 1, NRV_L4_NBG, NRV_L4_KA>), grid, blk, 0, h->stream, sa);)
-}
-
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
 // n + T - 1 events and the windows are formed on the device.  sat: the range-guard counter of the f16x2
 // signal branch for this group (one of h->d_sat's).
@@ -1187,11 +1162,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2; split planes for head_h2_kernel
       // no BatchNorm behind this layer (RAW); the one in front of it is folded into its weights;
       // 3 of its 10 weight k-blocks of 32 stay in LDS (96 KB; -3 %)
-#if NRV_L4_K
-      launch_lstm_h2k<64, 64>(h, 3, i0, o, T, n, tiles);
-#else
       launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles);
-#endif
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
