@@ -988,6 +988,16 @@ static void launch_lstm_h2w(nrv_handle* h, int layer, const ActView (&in0)[2], c
   NRV_ACT1(else hipLaunchKernelGGL((lstm_h2w_kernel<KQ0, KQ1, H, 1, NRV_L3_WS_NBG>), grid, blk, 0, h->stream, sa);)
 }
 
+// Diagnostic build only (-DNRV_STAMP=1): nrv_exp_only_stage(k) makes every later group launch ONLY stage k of the f16x2 mode
+// (0 signal branch, 2 32->64, 3 192->128, 4 256->64, 5 head; -1 all) on whatever the buffers hold - for per-kernel power /
+// clock readings (scripts/gpu_power_probe.sh).  The product has no such switch.
+#if NRV_STAMP
+static int g_only_stage = -1;
+#define NRV_RUN_STAGE(k) (g_only_stage < 0 || g_only_stage == (k))
+#else
+#define NRV_RUN_STAGE(k) true
+#endif
+
 // One launch group: n windows (n <= batch).  read_mode: inputs are per-event arrays holding
 // n + T - 1 events and the windows are formed on the device.  sat: the range-guard counter of the f16x2
 // signal branch for this group (one of h->d_sat's).
@@ -1061,7 +1071,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // still per (window, step): sized by the conv units alone its 512 units queued on 33 workgroups
       const int wg_c = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves, wg_l = (2 * ((n + 15) / 16) + kCnnRL1Waves - 1) / kCnnRL1Waves;
       const int wg = wg_c > wg_l ? wg_c : wg_l;
-      if (h2_fused_l2) {}
+      if (h2_fused_l2 || !NRV_RUN_STAGE(0)) {}
       else if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
       NRV_ACT1(else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);)
       h2_fused_l1 = true;
@@ -1116,7 +1126,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         ta.m[m] = Lstm2TModelParams{d.all + d.l2t_w, d.all + d.l2t_b, h->X1[m], h->X2[m], d.descale[1]};
       }
       dim3 grid((n + 63) / 64, 2, 2);
-      if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
+      if (!NRV_RUN_STAGE(2)) {}
+      else if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
       NRV_ACT1(else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);)
     }
     else if (h->split & 2) {
@@ -1141,7 +1152,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // behind it lives in the next layer's weights
       // (cell state in registers; 1 of its 10 weight k-blocks of 32 resident in LDS: 64 KB)
 #if NRV_L3_WS
-      launch_lstm_h2w<32, 16, 128>(h, 2, i0, i1, o, T, n, tiles);
+      if (NRV_RUN_STAGE(3)) launch_lstm_h2w<32, 16, 128>(h, 2, i0, i1, o, T, n, tiles);
 #else
       launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles);
 #endif
@@ -1162,7 +1173,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       float* const o[2] = {h->X2[0], h->X2[1]};           // X4 aliases X2; split planes for head_h2_kernel
       // no BatchNorm behind this layer (RAW); the one in front of it is folded into its weights;
       // 3 of its 10 weight k-blocks of 32 stay in LDS (96 KB; -3 %)
-      launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles);
+      if (NRV_RUN_STAGE(4)) launch_lstm_h2s<64, 0, 64, 2, 1, 1, 8, 2, 3, true>(h, 3, i0, none, o, T, n, tiles);
     } else if (h->split & 8) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[3], h->dm[1].all + h->dm[1].l_ws[3]};
       launch_lstm_split<64, 0, 64, 1, 2>(h, a, ws, tiles);
@@ -1183,7 +1194,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
         ha.m[m] = HeadH2ModelParams{d.all + d.h_w2, d.all + d.h_b2, h->X2[m], d.all + d.fw, d.all + d.fb, d.all + d.ow,
                                     d.all + d.ob, dp[m], da[m], d.hsc.c12, d.hsc.c23, d.hsc.c3o, d.C};
       }
-      hipLaunchKernelGGL(head_h2_kernel, dim3(tiles < 128 ? tiles : 128, 2), dim3(kHeadH2Threads), 0, h->stream, ha);
+      if (NRV_RUN_STAGE(5)) hipLaunchKernelGGL(head_h2_kernel, dim3(tiles < 128 ? tiles : 128, 2), dim3(kHeadH2Threads), 0, h->stream, ha);
       if ((rc = mark(6))) return rc;
       HIPCHK(h, hipGetLastError());
       return NRV_OK;
@@ -1754,6 +1765,10 @@ int nrv_prof_overhead(nrv_handle* h, double* us) {
 
 #if NRV_STAMP
 // diagnostic build only (not in include/nanorev.h): the phase stamps of the last lstm_h2s_kernel launches
+int nrv_exp_only_stage(int k) {
+  g_only_stage = k;
+  return 0;
+}
 int nrv_exp_stamps(void* dst, size_t bytes) {
   if (bytes > sizeof(nrv::nrv_stamp_buf)) bytes = sizeof(nrv::nrv_stamp_buf);
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(nrv::nrv_stamp_buf), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? (int)0 : -1;
