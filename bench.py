@@ -717,6 +717,12 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
         "executed_tflops": ach * PRODUCTS[precision],
         "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
     }
+    if precision == "f16x2":
+        # measured, not assumed (profiles/r04_clock_vs_fill.txt, profiles/r04_power_by_launch.json)
+        out["roofline" + suffix]["power_note"] = (
+            "this launch runs at the socket's 1400 W cap with the shader clock pulled down to ~1.85 GHz; the layers' inner loop "
+            "alone (weights from L2, fragments from LDS, chains of v_mfma_f32_16x16x32_f16 on every SIMD, random operands) "
+            "sustains 421-455 TFLOP/s f32-grade = 0.51-0.55 of `peak` whatever the fill of the matrix pipe")
     whole = flop_per_window(T) * B / (m["ms_per_step"] * 1e-3) / 1e12
     out["roofline_whole_step" + suffix] = {"achieved": whole, "peak": peak, "unit": "TFLOP/s", "frac": whole / peak,
                                            "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
