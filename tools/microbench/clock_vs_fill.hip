@@ -20,7 +20,10 @@ constexpr int kEntries = 40, kWBytes = kEntries * 2 * 1024;   // one wave's weig
 
 // STREAM: on top, every 6th entry one 1 KB request to a 1 GB buffer (every address once per launch: HBM) and every 8th entry
 // one 1 KB store: ~1.3 + 1.0 TB/s over the chip at full rate, the traffic of the 192->128 layer's launches
-template <int WAVES, int SLEEP, int STREAM = 0>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// MF32: the same operand traffic and the same FLOPs per entry through SIX v_mfma_f32_32x32x16_f16 (two 32-row tiles x three
+// products; half the A / B register reads per MAC) instead of twelve 16x16x32
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0>
 __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, const float* __restrict__ xsrc, float* out, int steps,
                                                 unsigned long long* clk, const char* big = nullptr, char* bigw = nullptr) {
   __shared__ __attribute__((aligned(16))) float xl[6 * 4 * 2 * 256];             // 48 KB of "activations"
@@ -31,6 +34,9 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
       const_cast<char*>(w) + (size_t)((blockIdx.x * 4 * WAVES + wave) & 31) * kWBytes, 0, kWBytes, 0x00020000);
   f32x4 acc[16];
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x16 acc32[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
   f32x4 b[4][2], a[4][2];
   for (int e = 0; e < 3; ++e)
     for (int t = 0; t < 2; ++t) b[e][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (e * 2 + t) * 1024, 0));
@@ -53,6 +59,9 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
         const int rt = m / 3, pr = m % 3;
         const f16x8 af = __builtin_bit_cast(f16x8, a[rt][pr == 1 ? 1 : 0]);
         const f16x8 bf = __builtin_bit_cast(f16x8, b[e % 4][pr == 0 ? 1 : 0]);
+        if constexpr (MF32) {
+          if (rt < 2) acc32[(e % 2) * 2 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc32[(e % 2) * 2 + rt], 0, 0, 0);
+        } else
         acc[(e % 4) * 4 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[(e % 4) * 4 + rt], 0, 0, 0);
         if (m < 2) {
           __builtin_amdgcn_sched_barrier(0);
@@ -73,23 +82,24 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
   float sink = 0.f;
   for (int i = 0; i < 16; ++i) sink += acc[i][0] + acc[i][3];
+  for (int i = 0; i < 4; ++i) sink += acc32[i][0] + acc32[i][15];
   if (sink == 12345.678f) out[threadIdx.x] = sink;
   if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
 static int g_sustain = 20;
 static char *g_big = nullptr, *g_bigw = nullptr;
-template <int WAVES, int SLEEP, int STREAM = 0>
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0>
 static void run(const char* name, const char* w, const float* x, float* out, unsigned long long* clk, int steps) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   // SUSTAIN launches back to back first (argv[1], default 20 = a 3.5 ms burst; 12000 = two seconds of continuous load, after
   // which the clock is the one the chip HOLDS under this load), then the timed 20
-  for (int i = 0; i < g_sustain; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+  for (int i = 0; i < g_sustain; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
   // socket power and shader clock while the queue is still full of these launches
   double watts = 0, mhz = 0;
   {
-    for (int i = 0; i < 4000; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+    for (int i = 0; i < 4000; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
     for (int rep = 0; rep < 2; ++rep) {                  // the second reading: the load has lasted a while
       FILE* f = popen("rocm-smi --showpower --showclocks 2>/dev/null", "r");
       char line[512];
@@ -104,7 +114,7 @@ static void run(const char* name, const char* w, const float* x, float* out, uns
   }
   hipEventRecord(e0);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -156,6 +166,9 @@ int main(int argc, char** argv) {
   run<2, 0, 1>("2 waves/SIMD, random + HBM stream (1 KB / 6 entries, store / 8)", w, x, out, clk, steps);
   run<2, 2, 1>("2 waves/SIMD, random + HBM stream, s_sleep 2", w, x, out, clk, steps);
   run<1, 0, 1>("1 wave/SIMD, random + HBM stream", w, x, out, clk, steps);
+  run<2, 0, 0, 1>("2 waves/SIMD, random, 32x32x16 tiles (same FLOPs, half the operand reads)", w, x, out, clk, steps);
+  run<2, 0, 1, 1>("2 waves/SIMD, random + HBM stream, 32x32x16 tiles", w, x, out, clk, steps);
+  run<1, 0, 0, 1>("1 wave/SIMD, random, 32x32x16 tiles", w, x, out, clk, steps);
   run<1, 2>("1 wave/SIMD, random, s_sleep 2 per entry", w, x, out, clk, steps);
   run<1, 4>("1 wave/SIMD, random, s_sleep 4 per entry", w, x, out, clk, steps);
   return 0;
