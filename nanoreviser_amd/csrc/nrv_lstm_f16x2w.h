@@ -45,9 +45,11 @@ namespace nrv {
 // scratch (24 B per lane) in front of the loop and fetches them back behind it; there is no scratch instruction inside the
 // loop (tools/isa_of.sh; a weight ring of 8 entries, or precomputing those addresses, puts some there).
 //
-// In-kernel stamps (scripts/gpu_stamps_w.py; profiles/r04*_stamps_lstm_h2w.json): 19.3 k cycles per step against
-// lstm_h2s_kernel's 23.6 k and 15.5 k of matrix pipe; the second half runs pipe-bound, the first at 80 % (group B's rec()
-// gets 23 % of the pipe while group A's runs, then shares the SIMD with group A's gate arithmetic).
+// In-kernel stamps (scripts/gpu_stamps_w.py; profiles/r04*_stamps_lstm_h2w.json): 18.8 k cycles per step against
+// lstm_h2s_kernel's 22.7-23.6 k and 15.5 k of matrix pipe; the second half runs pipe-bound, the first at 80 % (group B's rec()
+// gets 23 % of the pipe while group A's runs, then shares the SIMD with group A's gate arithmetic).  The time gained is a
+// fraction of the cycles gained: the launch runs at the socket's power cap and the fuller pipe holds a lower clock
+// (1.81 GHz against lstm_h2s_kernel's 2.03 on one box: 148.5 us against 152.9).
 //
 // Everything else is lstm_h2s_kernel's: operand layouts, the split h image, the scales, the packed weights
 // (pack_lstm_h2s with one unit half per wave), the raw copy-out of h x 2^13.
