@@ -23,7 +23,9 @@ constexpr int kEntries = 40, kWBytes = kEntries * 2 * 1024;   // one wave's weig
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // MF32: the same operand traffic and the same FLOPs per entry through SIX v_mfma_f32_32x32x16_f16 (two 32-row tiles x three
 // products; half the A / B register reads per MAC) instead of twelve 16x16x32
-template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0>
+// ORD = 1: the three products of a chain as (hi*lo, hi*hi, lo*hi) - each operand changes ONCE per chain - instead of
+// (hi*lo, lo*hi, hi*hi)
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0>
 __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, const float* __restrict__ xsrc, float* out, int steps,
                                                 unsigned long long* clk, const char* big = nullptr, char* bigw = nullptr) {
   __shared__ __attribute__((aligned(16))) float xl[6 * 4 * 2 * 256];             // 48 KB of "activations"
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int rt = m / 3, pr = m % 3;
-        const f16x8 af = __builtin_bit_cast(f16x8, a[rt][pr == 1 ? 1 : 0]);
+        const f16x8 af = __builtin_bit_cast(f16x8, a[rt][ORD ? (pr == 2 ? 1 : 0) : (pr == 1 ? 1 : 0)]);
         const f16x8 bf = __builtin_bit_cast(f16x8, b[e % 4][pr == 0 ? 1 : 0]);
         if constexpr (MF32) {
           if (rt < 2) acc32[(e % 2) * 2 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc32[(e % 2) * 2 + rt], 0, 0, 0);
@@ -89,17 +91,17 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
 
 static int g_sustain = 20;
 static char *g_big = nullptr, *g_bigw = nullptr;
-template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0>
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0>
 static void run(const char* name, const char* w, const float* x, float* out, unsigned long long* clk, int steps) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   // SUSTAIN launches back to back first (argv[1], default 20 = a 3.5 ms burst; 12000 = two seconds of continuous load, after
   // which the clock is the one the chip HOLDS under this load), then the timed 20
-  for (int i = 0; i < g_sustain; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+  for (int i = 0; i < g_sustain; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
   // socket power and shader clock while the queue is still full of these launches
   double watts = 0, mhz = 0;
   {
-    for (int i = 0; i < 4000; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+    for (int i = 0; i < 4000; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
     for (int rep = 0; rep < 2; ++rep) {                  // the second reading: the load has lasted a while
       FILE* f = popen("rocm-smi --showpower --showclocks 2>/dev/null", "r");
       char line[512];
@@ -114,7 +116,7 @@ static void run(const char* name, const char* w, const float* x, float* out, uns
   }
   hipEventRecord(e0);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -166,6 +168,9 @@ int main(int argc, char** argv) {
   run<2, 0, 1>("2 waves/SIMD, random + HBM stream (1 KB / 6 entries, store / 8)", w, x, out, clk, steps);
   run<2, 2, 1>("2 waves/SIMD, random + HBM stream, s_sleep 2", w, x, out, clk, steps);
   run<1, 0, 1>("1 wave/SIMD, random + HBM stream", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 1>("2 waves/SIMD, random, products ordered hi*lo, hi*hi, lo*hi", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 0>("2 waves/SIMD, random operands (again)", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 1>("2 waves/SIMD, random, products ordered hi*lo, hi*hi, lo*hi (again)", w, x, out, clk, steps);
   run<2, 0, 0, 1>("2 waves/SIMD, random, 32x32x16 tiles (same FLOPs, half the operand reads)", w, x, out, clk, steps);
   run<2, 0, 1, 1>("2 waves/SIMD, random + HBM stream, 32x32x16 tiles", w, x, out, clk, steps);
   run<1, 0, 0, 1>("1 wave/SIMD, random, 32x32x16 tiles", w, x, out, clk, steps);
