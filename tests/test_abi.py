@@ -37,6 +37,15 @@ def test_header_symbols_exported(lib):
     assert sorted(engine.SYMBOLS) == names
 
 
+def test_product_library_has_no_diagnostic_entry_points(lib):
+    """The stamp / stage-selector entry points (nrv_exp_*) exist only in diagnostic builds (-DNRV_STAMP=1, tools/lstm_exp.sh)."""
+    out = os.popen(f"nm -D --defined-only {engine.LIB_PATH}").read()
+    exported = sorted(set(re.findall(r"\b(nrv_[a-z_0-9]+)\b", out)))
+    assert exported, "nm found no nrv_* symbol"
+    assert not [n for n in exported if n.startswith("nrv_exp_")], exported
+    assert set(exported) == set(_declared()), sorted(set(exported) ^ set(_declared()))
+
+
 def test_host_helper_header_symbols_exported():
     """include/nanorev_host.h <-> libnanorev_host.so (plain C, gcc): every declared nrvh_* symbol is exported."""
     import __graft_entry__ as g
