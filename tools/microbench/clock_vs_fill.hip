@@ -36,6 +36,8 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
       const_cast<char*>(w) + (size_t)((blockIdx.x * 4 * WAVES + wave) & 31) * kWBytes, 0, kWBytes, 0x00020000);
   f32x4 acc[16];
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4 acci[16];
+  for (int i = 0; i < 16; ++i) acci[i] = i32x4{0, 0, 0, 0};
   f32x16 acc32[4];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
@@ -61,7 +63,10 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
         const int rt = m / 3, pr = m % 3;
         const f16x8 af = __builtin_bit_cast(f16x8, a[rt][ORD ? (pr == 2 ? 1 : 0) : (pr == 1 ? 1 : 0)]);
         const f16x8 bf = __builtin_bit_cast(f16x8, b[e % 4][pr == 0 ? 1 : 0]);
-        if constexpr (MF32) {
+        if constexpr (MF32 == 2) {                       // v_mfma_i32_16x16x64_i8: twice the MACs per instruction, same operand bytes
+          acci[(e % 4) * 4 + rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af), __builtin_bit_cast(i32x4, bf),
+                                                                          acci[(e % 4) * 4 + rt], 0, 0, 0);
+        } else if constexpr (MF32 == 1) {
           if (rt < 2) acc32[(e % 2) * 2 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc32[(e % 2) * 2 + rt], 0, 0, 0);
         } else
         acc[(e % 4) * 4 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[(e % 4) * 4 + rt], 0, 0, 0);
@@ -85,6 +90,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
   float sink = 0.f;
   for (int i = 0; i < 16; ++i) sink += acc[i][0] + acc[i][3];
   for (int i = 0; i < 4; ++i) sink += acc32[i][0] + acc32[i][15];
+  for (int i = 0; i < 16; ++i) sink += (float)(acci[i][0] + acci[i][3]);
   if (sink == 12345.678f) out[threadIdx.x] = sink;
   if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
@@ -171,6 +177,8 @@ int main(int argc, char** argv) {
   run<2, 0, 0, 0, 1>("2 waves/SIMD, random, products ordered hi*lo, hi*hi, lo*hi", w, x, out, clk, steps);
   run<2, 0, 0, 0, 0>("2 waves/SIMD, random operands (again)", w, x, out, clk, steps);
   run<2, 0, 0, 0, 1>("2 waves/SIMD, random, products ordered hi*lo, hi*hi, lo*hi (again)", w, x, out, clk, steps);
+  run<2, 0, 0, 2>("2 waves/SIMD, random BYTES, v_mfma_i32_16x16x64_i8 (x2 for ops)", w, x, out, clk, steps);
+  run<2, 0, 1, 2>("2 waves/SIMD, random bytes + HBM stream, i8 (x2 for ops)", w, x, out, clk, steps);
   run<2, 0, 0, 1>("2 waves/SIMD, random, 32x32x16 tiles (same FLOPs, half the operand reads)", w, x, out, clk, steps);
   run<2, 0, 1, 1>("2 waves/SIMD, random + HBM stream, 32x32x16 tiles", w, x, out, clk, steps);
   run<1, 0, 0, 1>("1 wave/SIMD, random, 32x32x16 tiles", w, x, out, clk, steps);
