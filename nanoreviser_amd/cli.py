@@ -19,7 +19,12 @@ Changed on purpose:
   * reads are sharded over the visible GPUs, one worker process per GPU, no collectives
     (--gpus, default all); --thread bounds the host-stage worker processes per GPU worker;
   * explicitly given --model{1,2}_predict_dir win over -S (in the reference -S always overrides
-    them, which makes those flags dead, :191-193).
+    them, which makes those flags dead, :191-193);
+  * --resume: a rerun skips the reads whose output file exists (the reference removes the output
+    directory and starts over, :196-201; SURVEY.md 5 "skip-if-exists is a free resume");
+  * each GPU worker is pinned to the cores of its GPU's NUMA node (`worker_cpus`), and a very long
+    read (BASELINE config 5) is split over the GPU workers by window range with a T-1-event halo
+    (`shard.split_read_windows`, `plan_splits`): still no device-to-device exchange.
 FASTQ qualities: the reviser has no Guppy qualities; each revised base gets
 Phred = -10 log10(1 - min(p_model1, p_model2)) of its call (capped 1..40), unrevised edge bases '#'.
 """
@@ -38,7 +43,7 @@ import numpy as np
 from . import h5lite
 from . import hostlib
 from . import hoststage as hs
-from .shard import shard_reads
+from .shard import shard_reads, split_read_windows
 from .weights import load_model
 
 VERSION = "1.0"
@@ -69,6 +74,12 @@ def get_args(argv: Optional[Sequence[str]] = None):
     p.add_argument("--gpus", type=int, default=0, help="GPUs to use (0 = all visible)")
     p.add_argument("--batch", type=int, default=4096, help="windows per device launch group")
     p.add_argument("--model_dir", default=None, help="root of model/<species>/ (default: next to the package)")
+    p.add_argument("--resume", action="store_true", default=False,
+                   help="skip every read whose <stem>_out.<format> already exists and is not empty (outputs are written "
+                        "through a temporary + rename, so an existing file is a finished one)")
+    p.add_argument("--split_reads_above", type=float, default=float(os.environ.get("NRV_SPLIT_READS_MB", "16")),
+                   help="with more than one GPU: a fast5 file above this many MB (~10 MB per 100 k events) has its "
+                        "window range split over the GPU workers, T-1 events of halo per slice (0 = never)")
     a = p.parse_args(argv)
     if a.virsion:
         print(f"The virsion of NanoReviser : {VERSION} ")
@@ -409,7 +420,16 @@ def write_read(args, fast5_fn: str, seq: str, qual: Optional[str]):
 
 kNativePoolMax = 4      # parser THREADS per GPU worker with the native host stage: 4 deliver 23 M bases/s (r04, 16-core cgroup),
                         # twice what one GPU takes; more only take the GIL from the engine thread (r04, 4000 reads end to
-                        # end: 2 / 4 / 8 / 16 threads = 11.2 / 11.3 / 10.2 / 9.3 M bases/s)
+                        # end: 2 / 4 / 8 / 16 threads = 11.2 / 11.3 / 10.2 / 9.3 M bases/s).  NRV_PARSER_THREADS_MAX overrides
+                        # it (INTEGRATION.md "Process-wide settings"); the cap was tuned at kSwitchInterval.
+kSwitchInterval = 2e-4  # CPython switch interval while the parser threads run (see process_files)
+
+
+def native_pool_max() -> int:
+    try:
+        return max(1, int(os.environ.get("NRV_PARSER_THREADS_MAX", kNativePoolMax)))
+    except ValueError:
+        return kNativePoolMax
 
 
 def parser_pool_size(threads: int, cores: int, gpu_workers: int, n_files: int, native: bool = False) -> int:
@@ -417,11 +437,12 @@ def parser_pool_size(threads: int, cores: int, gpu_workers: int, n_files: int, n
     (cores // gpu_workers, at least 1), at 32 (processes on the Python host stage) or kNativePoolMax (threads on the
     native one) and at the number of files."""
     share = max(1, cores // max(1, gpu_workers))
-    return max(1, min(int(threads), share, kNativePoolMax if native else 32, max(1, n_files)))
+    return max(1, min(int(threads), share, native_pool_max() if native else 32, max(1, n_files)))
 
 
 def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None],
-                  on_file: Optional[Callable[[str, bool], None]] = None, gpu_workers: int = 1) -> dict:
+                  on_file: Optional[Callable[[str, bool], None]] = None, gpu_workers: int = 1,
+                  core_share: Optional[int] = None) -> dict:
     """Revise `files` (names inside args.fast5_base_dir) with one engine.  The host stage (HDF5
     parsing, event collapse, signal segmentation) runs in worker PROCESSES (--thread of them, capped
     at the core count) that stay a bounded number of reads ahead of the device.
@@ -429,7 +450,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
     basecalls after a failure; revised=False also for files that could not be parsed at all).
     gpu_workers: how many such calls run on this host at the same time (one per GPU, `run_workers`): the cores are
     SHARED, so each call's parser pool gets usable_cores() // gpu_workers of them - eight workers on a 16-core cgroup
-    start 8 x 2 parser processes, not 8 x 16."""
+    start 8 x 2 parser processes, not 8 x 16.  core_share: this call's cores, when the caller has already
+    divided them (a GPU worker pinned to its NUMA slice: `_worker`)."""
     stats = {"reads": 0, "bases": 0, "failed": [], "host_s": 0.0, "engine_s": 0.0}
     # NRV_CLI_TRACE=1: where the wall time of this call goes (first device call, engine idle gaps, tail), to the log
     trace, t_start = ([] if os.environ.get("NRV_CLI_TRACE") else None), time.perf_counter()
@@ -465,7 +487,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         engines.append(reviser)
     stats_lock = threading.Lock()
     native_threads = hostlib.load() is not None and os.environ.get("NRV_HOST_THREADS", "1") != "0"
-    nworkers = parser_pool_size(int(args.thread), usable_cores(), gpu_workers, len(files), native=native_threads)
+    nworkers = parser_pool_size(int(args.thread), usable_cores(), gpu_workers, len(files), native=native_threads) \
+        if core_share is None else parser_pool_size(int(args.thread), int(core_share), 1, len(files), native=native_threads)
     stats["parser_workers"] = nworkers
     jobs = [(os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup,
              args.output_format == "fastq") for fn in files]
@@ -490,8 +513,15 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         # A pool thread coming back from its C call needs the GIL for ~0.1 ms of bookkeeping; with CPython's default
         # switch interval (5 ms) it waited that long behind whichever thread held it, and four parser threads delivered
         # what one does (r04: 3.2 M bases/s with 1, 4 or 8 threads; 10 / 13 M with 4 / 8 at 0.2 ms).  Restored on return.
-        old_switch = sys.getswitchinterval()
-        sys.setswitchinterval(2e-4)
+        # A process-global setting: only touched when the embedding caller has left it at CPython's default (a caller
+        # that tuned it keeps its value), NRV_SWITCH_INTERVAL=0 leaves it alone altogether, and it is restored on return.
+        try:
+            want = float(os.environ.get("NRV_SWITCH_INTERVAL", kSwitchInterval))
+        except ValueError:
+            want = kSwitchInterval
+        if want > 0 and abs(sys.getswitchinterval() - 0.005) < 1e-9:
+            old_switch = sys.getswitchinterval()
+            sys.setswitchinterval(want)
     elif nworkers > 1 and len(files) >= 4:
         import multiprocessing as mp
         # The workers never call BLAS; without a cap every one of them starts, at `import numpy`, an OpenBLAS pool sized
@@ -767,13 +797,166 @@ def _default_factory(args, device: int):
     return Reviser(load_model(p1), load_model(p2), device=device, batch=args.batch)
 
 
-def _worker(rank: int, world: int, args, files: List[str], q, factory=None):
-    """One GPU worker.  Streams a ("file", rank, fn, revised) record through the queue as each file's output
-    becomes final, so that the parent knows exactly which files are done should this process die."""
+def _cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (sysfs cpulist format)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_local_cpus(device: int, sysfs: str = "/sys") -> Optional[List[int]]:
+    """CPUs of the NUMA node HIP device `device` hangs on, or None when that cannot be told.  No HIP call: the KFD topology
+    lists the GPU nodes (simd_count > 0) in the order the runtime enumerates them; *_VISIBLE_DEVICES given as a plain
+    list of integers is honoured, any other form gives None."""
     try:
-        rv = (factory or _default_factory)(args, rank)
+        vis = None
+        for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            if os.environ.get(v, "") != "":
+                if vis is not None:
+                    return None                        # two layers of re-mapping: not guessed
+                vis = [int(x) for x in os.environ[v].split(",")]
+        if vis is not None:
+            device = vis[device]
+        base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        pr = gpus[device]
+        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
+        dev = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+        try:
+            cpus = _cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        except OSError:
+            cpus = []
+        if not cpus:
+            node = int(open(os.path.join(dev, "numa_node")).read())
+            if node < 0:
+                return None
+            cpus = _cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def worker_cpus(rank: int, world: int, devices: Optional[Sequence[int]] = None, allowed: Optional[Sequence[int]] = None,
+                sysfs: str = "/sys") -> Optional[List[int]]:
+    """The cores GPU worker `rank` of `world` pins itself to (NanoReviser.py:203-219 leaves its Pool wherever the kernel
+    puts it), or None = leave the affinity alone.  The cores this process may use are divided so that each worker gets
+    cores of ITS GPU's NUMA node (fast5 buffers, pinned staging memory and the HIP runtime's threads then sit next to the
+    GPU's PCIe root); workers whose GPUs share a node share its cores evenly; without NUMA information the allowed
+    cores are cut into `world` contiguous slices.  NRV_CPU_AFFINITY=0 turns it off; fewer than two cores per worker: off."""
+    if os.environ.get("NRV_CPU_AFFINITY", "1") == "0" or world < 1:
+        return None
+    try:
+        allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if len(allowed) < 2 * world:
+        return None
+    devices = list(devices) if devices is not None else list(range(world))
+    aset = set(allowed)
+    local = []
+    for r in range(world):
+        c = gpu_local_cpus(devices[r], sysfs)
+        c = sorted(aset.intersection(c)) if c else None
+        local.append(tuple(c) if c else None)
+    if any(c is None for c in local):
+        lo, hi = rank * len(allowed) // world, (rank + 1) * len(allowed) // world
+        return allowed[lo:hi]
+    mine = local[rank]
+    peers = [r for r in range(world) if local[r] == mine]
+    k, n = peers.index(rank), len(peers)
+    part = list(mine[k * len(mine) // n:(k + 1) * len(mine) // n])
+    return part if len(part) >= 2 else None
+
+
+def share_device() -> bool:
+    """NRV_SHARE_DEVICE=1: worker rank r drives device r % device_count - a 1-GPU box rehearsing the N-worker command
+    line with the real engine (bench.py --share-device, tests/test_gpu_multirank.py).  Never the default."""
+    return os.environ.get("NRV_SHARE_DEVICE", "0") == "1"
+
+
+def plan_splits(names: Sequence[str], sizes: Sequence[int], world: int, split_mb: float):
+    """Which files are revised whole and which by window range: a fast5 above `split_mb` MB is cut into
+    min(world, ceil(size / split_mb)) slices (file size is the only thing known before parsing: ~100 bytes per event).
+    Returns (units, unit_sizes): a unit is a file name or (file name, slice, slices)."""
+    units, usz = [], []
+    lim = int(split_mb * (1 << 20)) if split_mb and split_mb > 0 else 0
+    for fn, sz in zip(names, sizes):
+        parts = min(world, -(-int(sz) // lim)) if lim and world > 1 and sz > lim else 1
+        if parts <= 1:
+            units.append(fn)
+            usz.append(int(sz))
+        else:
+            for k in range(parts):
+                units.append((fn, k, parts))
+                usz.append(int(sz) // parts)
+    return units, usz
+
+
+def revise_part(args, reviser, fn: str, k: int, parts: int):
+    """Slice k of `parts` of ONE read (BASELINE config 5): the read is parsed here (every worker that holds a
+    slice parses the file: the host stage is cheap beside 100 k+ windows), `shard.split_read_windows` gives the event
+    range [lo, hi) whose windows are exactly windows [lo, hi - T) of the read, and those events alone go to the device -
+    whole raw samples, sliced starts / features, so every window is cut and computed as in the unsplit read.
+    Returns (payload, error): the slice's calls (+ the original bases and the Fastq record with slice 0)."""
+    job = (os.path.join(args.fast5_base_dir, fn), fn, args.basecall_group, args.basecall_subgroup, True)
+    _, rt, fq, err, _ = _load_one(job)
+    if rt is None or err is not None:
+        return None, err or "unreadable"
+    T, N = int(reviser.T), len(rt.feat_ev)
+    lo, hi = split_read_windows(N, T, parts)[k]
+    if hi > lo:
+        if isinstance(rt, hs.RawReadTensors):
+            p1, p2, a1, a2 = reviser.predict_reads_raw([rt.raw], [rt.starts[lo:hi]], [rt.feat_ev[lo:hi]], [rt.shift], [rt.scale])
+        else:
+            p1, p2, a1, a2 = reviser.predict_read(rt.sig_ev[lo:hi], rt.feat_ev[lo:hi])
+    else:
+        p1, p2 = np.zeros((0, 6), np.float32), np.zeros((0, 5), np.float32)
+        a1 = a2 = np.zeros(0, np.int8)
+    qc = phred_chars(p1, p2, a1, a2) if args.output_format == "fastq" and len(a1) else None
+    out = {"T": T, "n_ev": N, "lo": lo, "a1": np.array(a1, np.int8), "a2": np.array(a2, np.int8), "qc": qc}
+    if k == 0:
+        out["bases"], out["fq"] = np.asarray(rt.bases), fq
+    return out, None
+
+
+def _worker(rank: int, world: int, args, files: List[str], q, factory=None, parts=()):
+    """One GPU worker.  Streams a ("file", rank, fn, revised) record through the queue as each file's output
+    becomes final, so that the parent knows exactly which files are done should this process die; the slices of
+    split reads (`parts`: (fn, slice, slices)) go first - they are the long poles - and come back as ("part", ...)."""
+    try:
+        cores_all = usable_cores()
+        ndev = None
+        if share_device():
+            from .engine import device_count
+            ndev = max(1, device_count())
+        device = rank % ndev if ndev else rank
+        cpus = worker_cpus(rank, world, [r % ndev if ndev else r for r in range(world)])
+        share = None
+        if cpus:
+            try:
+                os.sched_setaffinity(0, cpus)          # before the engine: the HIP runtime's threads inherit it
+                share = max(1, min(len(cpus), cores_all // max(1, world)))
+            except OSError:
+                cpus = None
+        rv = (factory or _default_factory)(args, device)
+        for fn, k, n in parts:
+            try:
+                payload, err = revise_part(args, rv, fn, k, n)
+            except Exception as e:
+                payload, err = None, repr(e)
+            q.put(("part", rank, fn, k, payload, err))
         st = process_files(args, files, rv, print, on_file=lambda fn, ok: q.put(("file", rank, fn, bool(ok))),
-                           gpu_workers=world)
+                           gpu_workers=world, core_share=share)
+        st["cpus"] = len(cpus) if cpus else 0
         rv.close()
         q.put(("done", rank, st, None))
     except BaseException as e:           # engine could not be created: loud, no silent fallback
@@ -800,19 +983,54 @@ def write_originals(args, files: Sequence[str], log: Callable[[str], None]) -> L
     return done
 
 
-def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2):
+def finish_split_reads(args, split_fns: dict, parts_got: dict, log: Callable[[str], None]):
+    """Parent side of the split reads: the slices' calls in slice order are the read's calls (window i of slice k is
+    window lo_k + i of the read), merged and written exactly as an unsplit read's.  A read with a slice missing (its
+    worker died) or failed gets its original basecalls (NanoReviser.py:146-152).  Returns (bases written, failed names)."""
+    spec, nb, failed = _OutSpec(args), 0, []
+    for fn, n in sorted(split_fns.items()):
+        got = parts_got.get(fn, {})
+        pl = [got.get(k, (None, "slice never came back"))[0] for k in range(n)]
+        err = next((e for k in range(n) for e in [got.get(k, (None, "slice never came back"))[1]] if e), None)
+        ok = n > 0 and err is None and all(p is not None for p in pl) and "bases" in pl[0]
+        if ok:                                         # every worker parsed the same file: same event count, slices abut
+            T, N = pl[0]["T"], pl[0]["n_ev"]
+            want = split_read_windows(N, T, n)
+            ok = all(p["n_ev"] == N and p["T"] == T and p["lo"] == want[k][0] and len(p["a1"]) == max(want[k][1] - want[k][0] - T, 0)
+                     for k, p in enumerate(pl))
+            err = None if ok else "slices do not tile the read"
+        if ok:
+            a1, a2 = np.concatenate([p["a1"] for p in pl]), np.concatenate([p["a2"] for p in pl])
+            qc = np.concatenate([p["qc"] if p["qc"] is not None else np.zeros(0, np.uint8) for p in pl]) \
+                if args.output_format == "fastq" and len(a1) else None
+            w, e2 = (_finish_native if hostlib.load() is not None else _finish_in_worker)(spec, T, fn, pl[0]["bases"], a1, a2, qc)
+            if e2 is None:
+                nb += w
+                log(f"[p:::] {fn.split('.')[0]}_out.{args.output_format} was saved...... ({n} slices)")
+                continue
+            err = e2
+        log(f"[！！！Error] revising {fn.split('.')[0]}: {err}; writing the original basecalls")
+        write_originals(args, [fn], log)
+        failed.append(fn)
+    return nb, failed
+
+
+def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2, part_shards=None, parts_out=None):
     """One worker process per GPU (NanoReviser.py:203-219 fans out the same way, one Pool task per
     file).  The parent never blocks on the result queue alone: a worker that dies hard - a HIP memory
     fault aborts the process, a segfault, the OOM killer - posts nothing, so liveness is polled next to
     the queue.  The other workers finish their own shards (reads are independent).
     Returns [(rank, stats or None, error or None, files)] with files = {fn: revised} for every file the
-    worker reported final before it ended (file existence is never used as evidence)."""
+    worker reported final before it ended (file existence is never used as evidence).
+    part_shards[r]: the (fn, slice, slices) units of worker r; their results are collected into parts_out
+    {fn: {slice: (payload, error)}} for `finish_split_reads`."""
     import multiprocessing as mp
     import queue as _q
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     world = len(shards)
-    procs = [ctx.Process(target=_worker, args=(r, world, args, shards[r], q, factory)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, args, shards[r], q, factory,
+                                               tuple(part_shards[r]) if part_shards else ())) for r in range(world)]
     for pr in procs:
         pr.start()
     res = {}
@@ -824,6 +1042,9 @@ def run_workers(args, shards: List[List[str]], factory=None, poll_s: float = 0.2
                 msg = q.get(timeout=timeout)
                 if msg[0] == "file":
                     files[msg[1]][msg[2]] = msg[3]
+                elif msg[0] == "part":
+                    if parts_out is not None:
+                        parts_out.setdefault(msg[2], {})[msg[3]] = (msg[4], msg[5])
                 else:
                     _, rank, st, err = msg
                     res[rank] = (rank, st, err)
@@ -862,6 +1083,23 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
     names = sorted(f for f in os.listdir(args.fast5_base_dir) if f.endswith(".fast5"))
     os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.time()
+    kept_failed, n_resumed = [], 0
+    if args.resume:
+        # A finished read is a non-empty <stem>_out.<fmt>: outputs only ever appear by rename of a complete temporary.
+        # Reads an earlier run wrote UNREVISED stay in the failed-reads file (their output exists, so they are skipped).
+        def done(f):
+            try:
+                return os.path.getsize(out_name(args.output_dir, f, args.output_format)) > 0
+            except OSError:
+                return False
+        skip = {f for f in names if done(f)}
+        try:
+            with open(os.path.join(args.output_dir, args.failed_reads_filename)) as fp:
+                kept_failed = [ln.strip() for ln in fp if ln.strip() in skip]
+        except OSError:
+            pass
+        n_resumed, names = len(skip), [f for f in names if f not in skip]
+        print(f"[s:::] --resume: {n_resumed} reads already have their output, {len(names)} to do")
     if reviser_factory is not None:       # in-process (tests / embedding): one engine, no sharding
         rv = reviser_factory(args, 0)
         stats = [process_files(args, names, rv, print)]
@@ -878,9 +1116,13 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         if ndev == 0:
             print("[！！！Error] no MI355X / HIP device visible: the reviser has no CPU path", file=sys.stderr)
             return 2
-        world = min(args.gpus or ndev, ndev, max(1, len(names)))
+        # workers: --gpus (default: every visible device), never more than there are units of work; NRV_SHARE_DEVICE=1
+        # (rehearsal) lets --gpus exceed the device count, worker r then drives device r % count
+        want = min(args.gpus or ndev, args.gpus if (share_device() and args.gpus) else ndev)
         sizes = [os.path.getsize(os.path.join(args.fast5_base_dir, f)) for f in names]
-        parts = shard_reads(sizes, world)
+        units, usz = plan_splits(names, sizes, want, args.split_reads_above)
+        world = max(1, min(want, len(units)))
+        parts = shard_reads(usz, world)
         if world == 1:
             made = []
 
@@ -891,9 +1133,17 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
             for rv in made:
                 rv.close()
         else:
-            shards = [[names[i] for i in parts[r]] for r in range(world)]
-            res = run_workers(args, shards, worker_factory)
+            shards = [[units[i] for i in parts[r] if isinstance(units[i], str)] for r in range(world)]
+            part_shards = [[units[i] for i in parts[r] if not isinstance(units[i], str)] for r in range(world)]
+            split_fns = {u[0]: u[2] for u in units if not isinstance(u, str)}      # file -> slices
+            parts_got = {}
+            res = run_workers(args, shards, worker_factory, part_shards=part_shards, parts_out=parts_got)
             stats = [s for _, s, _, _ in res if s is not None]
+            if split_fns:
+                nb_split, failed_split = finish_split_reads(args, split_fns, parts_got, print)
+                stats.append({"reads": len(split_fns), "bases": nb_split, "failed": failed_split, "host_s": 0.0, "engine_s": 0.0})
+                if failed_split:
+                    rc = 3
             for r, s_, e, final in res:
                 if s_ is None:                        # the shard's files still get an output + a failed_reads entry
                     print(f"[！！！Error] GPU worker {r} failed: {e}; writing the original basecalls of its "
@@ -904,7 +1154,7 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
                     lost += [f for f, ok in final.items() if not ok]
                     stats.append({"reads": len(shards[r]), "bases": 0, "failed": lost, "host_s": 0.0, "engine_s": 0.0})
                     rc = 3
-    failed = [f for s in stats for f in s["failed"]]
+    failed = kept_failed + [f for s in stats for f in s["failed"]]
     with open(os.path.join(args.output_dir, args.failed_reads_filename), "w") as fp:
         fp.write("".join(f + "\n" for f in failed))
     dt = time.time() - t0

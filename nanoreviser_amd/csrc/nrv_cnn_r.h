@@ -221,6 +221,9 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
   // NaN, and the ReLU behind conv2 (v_med3) turns a NaN into 0 - a silently wrong feature that the check on S cannot
   // see.  So the centre samples (every position of the window is one lane's centre sample exactly once) feed a running
   // maximum, one v_med3_f32 each, which is compared once per unit with the static bound of upload_model (ep[24]).
+  // This guard covers FINITE overflow only: v_med3_f32 returns min3 when an operand is NaN, so a NaN sample drops out
+  // of xmax (and +Inf is clamped to 3e38, still above every bound).  NaN samples are caught by the check on S, which a
+  // NaN always reaches through conv2 and the dense layer (tests/test_gpu_range.py::test_nan_and_inf_samples pins both).
   float xmax = 0.f;
   auto conv1_store = [&](lds_h* d, float xm, float xc, float xp) __attribute__((always_inline)) {
     xmax = __builtin_amdgcn_fmed3f(__builtin_fabsf(xc), xmax, 3.0e38f);

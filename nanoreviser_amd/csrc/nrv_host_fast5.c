@@ -19,6 +19,7 @@
  * call per file, no Python object touched: ctypes releases the GIL, so the callers are THREADS of one process. */
 #include <dlfcn.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -219,6 +220,7 @@ static int read_dset(Buf* b, uint64_t addr, Dset* ds) {
     for (int i = 0; i < rank; ++i) ds->dims[i] = U(b, p + 8 * i, 8);
   }
   if (parse_type(b, ty->off, &ds->t, ds->mem, &ds->nmem, 24, &ds->esize) < 0) return -1;
+  if (ds->esize <= 0 || ds->esize > (1 << 20)) return -1;     /* an element of no bytes divides by zero further down */
   { /* layout */
     const uint64_t off = la->off;
     const int ver = (int)U(b, off, 1);
@@ -258,25 +260,33 @@ static int read_dset(Buf* b, uint64_t addr, Dset* ds) {
   return b->bad ? -1 : 0;
 }
 
-/* inflate: libdeflate when the image has it (about twice zlib's speed; the same bytes), zlib otherwise */
+/* inflate: libdeflate when the image has it (about twice zlib's speed; the same bytes), zlib otherwise.  The callers
+ * are threads: the library is looked up once (pthread_once), each thread owns one decompressor, freed when it ends. */
 typedef void* (*ld_alloc_t)(void);
+typedef void (*ld_free_t)(void*);
 typedef int (*ld_dec_t)(void*, const void*, size_t, void*, size_t, size_t*);
 static ld_alloc_t ld_alloc;
+static ld_free_t ld_free;
 static ld_dec_t ld_dec;
-static int ld_state;          /* 0 not tried, 1 usable, -1 absent */
-static __thread void* ld_ctx;
+static int ld_usable;
+static pthread_once_t ld_once = PTHREAD_ONCE_INIT;
+static pthread_key_t ld_key;
+static void ld_ctx_free(void* c) { if (c && ld_free) ld_free(c); }
+static void ld_init(void) {
+  void* h = getenv("NRV_NO_LIBDEFLATE") ? 0 : dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+  ld_alloc = h ? (ld_alloc_t)dlsym(h, "libdeflate_alloc_decompressor") : 0;
+  ld_free = h ? (ld_free_t)dlsym(h, "libdeflate_free_decompressor") : 0;
+  ld_dec = h ? (ld_dec_t)dlsym(h, "libdeflate_zlib_decompress") : 0;
+  ld_usable = ld_alloc && ld_free && ld_dec && pthread_key_create(&ld_key, ld_ctx_free) == 0;
+}
 static int inflate_into(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* got) {
-  if (ld_state == 0) {
-    void* h = getenv("NRV_NO_LIBDEFLATE") ? 0 : dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
-    ld_alloc_t a = h ? (ld_alloc_t)dlsym(h, "libdeflate_alloc_decompressor") : 0;
-    ld_dec_t d = h ? (ld_dec_t)dlsym(h, "libdeflate_zlib_decompress") : 0;
-    if (a && d) { ld_alloc = a; ld_dec = d; __sync_synchronize(); ld_state = 1; } else ld_state = -1;
-  }
-  if (ld_state == 1) {
-    if (!ld_ctx) ld_ctx = ld_alloc();
-    if (ld_ctx) {
+  pthread_once(&ld_once, ld_init);
+  if (ld_usable) {
+    void* ctx = pthread_getspecific(ld_key);
+    if (!ctx) { ctx = ld_alloc(); if (ctx && pthread_setspecific(ld_key, ctx)) { ld_free(ctx); ctx = 0; } }
+    if (ctx) {
       size_t out = 0;
-      const int r = ld_dec(ld_ctx, src, n, dst, cap, &out);      /* 0 = LIBDEFLATE_SUCCESS */
+      const int r = ld_dec(ctx, src, n, dst, cap, &out);         /* 0 = LIBDEFLATE_SUCCESS */
       if (r == 0) { *got = out; return 0; }
       /* short output buffer or anything else: let zlib have the last word */
     }
@@ -333,7 +343,12 @@ static int walk_chunks(Buf* b, const Dset* ds, uint64_t node, uint8_t* out, uint
 /* raw bytes of a dataset (caller frees *out when *owned) */
 static int dset_bytes(Buf* b, const Dset* ds, const uint8_t** out, size_t* nbytes, int* owned) {
   uint64_t n = 1;
-  for (int i = 0; i < ds->rank; ++i) n *= ds->dims[i];
+  if (ds->esize <= 0) return -1;
+  for (int i = 0; i < ds->rank; ++i) {                  /* n x esize must not wrap: a file is never 2^40 bytes */
+    if (ds->dims[i] != 0 && n > ((uint64_t)1 << 40) / ds->dims[i]) return -1;
+    n *= ds->dims[i];
+  }
+  if (n > ((uint64_t)1 << 40) / (uint64_t)ds->esize) return -1;
   const uint64_t want = n * (uint64_t)ds->esize;
   *owned = 0;
   if (ds->layout == 0 || ds->layout == 1) {
@@ -408,7 +423,8 @@ static int version_is_new(Buf* b, uint64_t gaddr) {
   return 0;                                             /* no attribute: h5lite defaults to "0.0" = old */
 }
 
-static int64_t load_int(const uint8_t* p, const Prim* t) {
+static int int_size_ok(const Prim* t) { return t->size == 1 || t->size == 2 || t->size == 4 || t->size == 8; }
+static int64_t load_int(const uint8_t* p, const Prim* t) {       /* callers check int_size_ok first */
   uint64_t v = 0;
   memcpy(&v, p, (size_t)t->size);
   if (t->is_signed) { const int sh = 64 - 8 * t->size; return ((int64_t)(v << sh)) >> sh; }
@@ -515,6 +531,15 @@ int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, i
     if (!m_start || !m_mean || !m_stdv || !m_state || !m_move) break;
     if (m_start->t.cls != 0 || m_move->t.cls != 0 || m_state->t.cls != 3 || m_state->t.size < 3) { why = "Events fields of another type"; break; }
     if (m_mean->t.cls != 1 || m_stdv->t.cls != 1 || m_mean->t.size != 4 || m_stdv->t.size != 4) { why = "Events mean / stdv are not float32"; break; }
+    /* sizes and offsets come from the FILE: every field that is read must lie inside a row, integers must fit load_int */
+    if (!int_size_ok(&m_start->t) || !int_size_ok(&m_move->t)) { why = "Events integer fields of an unusual width"; break; }
+    {
+      const Member* used[5] = {m_start, m_mean, m_stdv, m_state, m_move};
+      int inside = ev.esize > 0;
+      for (int i = 0; i < 5 && inside; ++i)
+        inside = used[i]->off >= 0 && used[i]->t.size > 0 && (int64_t)used[i]->off + used[i]->t.size <= (int64_t)ev.esize;
+      if (!inside) { why = "Events field outside its row"; break; }
+    }
     if (dset_bytes(b, &ev, &ev_bytes, &ev_n, &ev_owned)) break;
     if (dset_bytes(b, &sg, &sig_bytes, &sig_n, &sig_owned)) break;
     const int64_t n_ev_in = (int64_t)ev.dims[0], es = ev.esize, L = (int64_t)sg.dims[0];
@@ -710,8 +735,11 @@ int nrvh_finish_read(const char* bases, int64_t n_ev, const int8_t* a1, const in
     memcpy(text + p, qual, q); p += q;
   }
   free(qual);
+  /* the finishers are threads of one process and two reads can map to one dst (the stem ends at the first '.'): the
+   * temporary is unique per CALL, so the writes never interleave and the last rename wins whole */
+  static unsigned long tmp_serial;
   char tmp[4200];
-  if (snprintf(tmp, sizeof tmp, "%s.tmp%ld", dst, (long)getpid()) >= (int)sizeof tmp) { free(text); return NRVH_E_ARG; }
+  if (snprintf(tmp, sizeof tmp, "%s.tmp%ld_%lu", dst, (long)getpid(), __atomic_add_fetch(&tmp_serial, 1, __ATOMIC_RELAXED)) >= (int)sizeof tmp) { free(text); return NRVH_E_ARG; }
   FILE* fp = fopen(tmp, "wb");
   if (!fp) { free(text); return NRVH_E_IO; }
   const int ok = fwrite(text, 1, p, fp) == p;

@@ -10,7 +10,7 @@ import pytest
 from conftest import GOLD, load_read
 from nanoreviser_amd import cli
 from nanoreviser_amd import hoststage as hs
-from echo_engine import (EchoEngine, _ExclusiveEcho, exclusive_factory, echo_factory, dying_factory, dying_midway_factory, broken_factory,
+from echo_engine import (HashEngine, hash_factory, hash_dies_on_slice_factory, EchoEngine, _ExclusiveEcho, exclusive_factory, echo_factory, dying_factory, dying_midway_factory, broken_factory,
                          fails_then_dies_factory)
 
 FAST5 = os.path.join(GOLD, "fast5")
@@ -174,6 +174,114 @@ def test_multi_gpu_worker_that_dies_does_not_hang_the_cli(tmp_path, factory):
     assert len(failed) == 1 and failed[0] in files                     # the dead worker's single read
     for fn in files:                                                   # every read still has an output
         assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + _orig(fn)
+
+
+def test_resume_skips_reads_whose_output_exists(tmp_path):
+    """--resume (NanoReviser.py:196-201 removes the output directory and reruns everything; SURVEY.md 5: one file per
+    read makes skip-if-exists a free resume): finished reads are not touched, not even parsed; an EMPTY output is not a
+    finished one; a read the earlier run wrote unrevised stays in the failed-reads file."""
+    import shutil
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    for i in range(6):
+        shutil.copy(src[i % 2], d / f"r{i}.fast5")
+    (d / "broken.fast5").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\x00" * 64)
+    out = str(tmp_path) + "/o/"
+    os.makedirs(out)
+    open(out + "r1_out.fasta", "w").write("FINISHED EARLIER")          # kept as it is
+    open(out + "r2_out.fasta", "w").write("")                           # empty: not finished
+    open(out + "r4_out.fasta", "w").write(">r4.fast5\nACGT")           # an earlier run's fallback output ...
+    open(out + "failed_reads.txt", "w").write("r4.fast5\nr5.fast5\n")   # ... listed as failed; r5 has no output: redone
+    eng = EchoEngine()
+    assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1", "--resume"], reviser_factory=lambda a, dev: eng) == 0
+    assert open(out + "r1_out.fasta").read() == "FINISHED EARLIER" and open(out + "r4_out.fasta").read() == ">r4.fast5\nACGT"
+    for i in (0, 2, 3, 5):
+        assert open(out + f"r{i}_out.fasta").read() == f">r{i}.fast5\n" + _orig(os.path.basename(src[i % 2]))
+    assert open(out + "failed_reads.txt").read().split() == ["r4.fast5", "broken.fast5"]
+    assert not [f for f in os.listdir(out) if ".tmp" in f]
+    # a second --resume has nothing left but the unparsable file; without the flag everything is redone
+    eng2 = EchoEngine()
+    assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1", "--resume"], reviser_factory=lambda a, dev: eng2) == 0
+    assert eng2.calls == 0 and open(out + "failed_reads.txt").read().split() == ["r4.fast5", "broken.fast5"]
+    assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1"], reviser_factory=lambda a, dev: EchoEngine()) == 0
+    assert open(out + "r1_out.fasta").read() == ">r1.fast5\n" + _orig(os.path.basename(src[1]))
+    assert open(out + "failed_reads.txt").read().split() == ["broken.fast5"]
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+def test_long_read_is_split_over_the_gpu_workers_with_a_halo(tmp_path, fmt):
+    """BASELINE config 5 / SURVEY 8e: a read too long for one worker's share is cut by WINDOW RANGE, T-1 events of halo
+    (shard.split_read_windows), every slice revised by another worker process, the parent merges.  The engine's calls
+    depend on the centre event (deletions, insertions, disagreements included), so the files equal the unsplit run's
+    byte for byte only if the slices tile the read exactly.  Threshold 0.2 MB: the 0.7-0.9 MB fixtures become 3 slices."""
+    one, three = str(tmp_path) + "/one/", str(tmp_path) + "/three/"
+    assert cli.main(["-d", FAST5, "-o", one, "-S", "ecoli", "-F", fmt, "--thread", "1"], reviser_factory=lambda a, dev: HashEngine()) == 0
+    units, _ = cli.plan_splits(["a", "b"], [900_000, 100_000], 3, 0.2)
+    assert units == [("a", 0, 3), ("a", 1, 3), ("a", 2, 3), "b"]
+    assert cli.plan_splits(["a"], [900_000], 1, 0.2)[0] == ["a"] and cli.plan_splits(["a"], [900_000], 8, 0)[0] == ["a"]
+    assert cli.main(["-d", FAST5, "-o", three, "-S", "ecoli", "-F", fmt, "--thread", "1", "--split_reads_above", "0.2"],
+                    worker_factory=hash_factory, world=3) == 0
+    names = sorted(f for f in os.listdir(one) if f.endswith("_out." + fmt))
+    assert len(names) == 2 and names == sorted(f for f in os.listdir(three) if f.endswith("_out." + fmt))
+    for f in names:
+        a, b = open(one + f, "rb").read(), open(three + f, "rb").read()
+        assert a == b and len(a) > 6000, f
+    orig = _orig(sorted(os.listdir(FAST5))[0])
+    assert open(one + names[0]).read().split("\n")[1] != orig               # the hash engine really edits the read
+    assert open(three + "failed_reads.txt").read() == ""
+
+
+def test_split_read_whose_worker_dies_gets_its_original_bases(tmp_path):
+    out = str(tmp_path) + "/o/"
+    rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1", "--split_reads_above", "0.4"],
+                  worker_factory=hash_dies_on_slice_factory, world=2)
+    assert rc == 3
+    files = sorted(os.listdir(FAST5))
+    assert sorted(open(out + "failed_reads.txt").read().split()) == files       # both reads had a slice on the dead worker
+    for fn in files:
+        assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + _orig(fn)
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: [(domain, bus, numa cpulist)] -> a /sys tree with a CPU node 0 and one KFD node per GPU."""
+    nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    for i, (dom, bus, cpus) in enumerate(gpus):
+        (nodes / str(i + 1)).mkdir()
+        (nodes / str(i + 1) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndomain {dom}\nlocation_id {bus << 8}\n")
+        dev = root / "bus" / "pci" / "devices" / ("%04x:%02x:00.0" % (dom, bus))
+        dev.mkdir(parents=True)
+        (dev / "local_cpulist").write_text(cpus + "\n")
+
+
+def test_gpu_workers_are_pinned_to_their_gpus_numa_cores(tmp_path, monkeypatch):
+    """VERDICT r04 #1c: eight workers on a two-socket node: each gets cores of ITS GPU's node, workers that share a node
+    share it evenly, the slices are disjoint and stay inside what the process may use."""
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "NRV_CPU_AFFINITY"):
+        monkeypatch.delenv(v, raising=False)
+    _fake_sysfs(tmp_path, [(0, 0x05 + 8 * i, "0-31,64-95" if i < 4 else "32-63,96-127") for i in range(8)])
+    sysfs = str(tmp_path)
+    assert cli.gpu_local_cpus(0, sysfs) == list(range(0, 32)) + list(range(64, 96))
+    assert cli.gpu_local_cpus(7, sysfs)[0] == 32 and cli.gpu_local_cpus(8, sysfs) is None
+    sets = [cli.worker_cpus(r, 8, allowed=range(128), sysfs=sysfs) for r in range(8)]
+    assert all(len(c) == 16 for c in sets) and len(set().union(*map(set, sets))) == 128
+    assert all(set(c) <= set(cli.gpu_local_cpus(r, sysfs)) for r, c in enumerate(sets))
+    # a cgroup that grants 16 of those cores: 2 each, still on the right node where the node has any
+    few = [cli.worker_cpus(r, 8, allowed=list(range(0, 8)) + list(range(32, 40)), sysfs=sysfs) for r in range(8)]
+    assert few[0] == [0, 1] and few[3] == [6, 7] and few[4] == [32, 33] and few[7] == [38, 39]
+    # all workers on ONE device (rehearsal): its node's cores divided among them
+    shared = [cli.worker_cpus(r, 4, devices=[0] * 4, allowed=range(128), sysfs=sysfs) for r in range(4)]
+    assert [len(c) for c in shared] == [16] * 4 and not set(shared[0]) & set(shared[1])
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6,7")                    # a re-mapped device list is honoured
+    assert cli.gpu_local_cpus(0, sysfs)[0] == 32
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # no topology (this container): contiguous slices of what is allowed; too few cores or NRV_CPU_AFFINITY=0: hands off
+    assert cli.worker_cpus(1, 2, allowed=range(8), sysfs=str(tmp_path / "none")) == [4, 5, 6, 7]
+    assert cli.worker_cpus(0, 8, allowed=range(8), sysfs=sysfs) is None
+    monkeypatch.setenv("NRV_CPU_AFFINITY", "0")
+    assert cli.worker_cpus(0, 2, allowed=range(128), sysfs=sysfs) is None
 
 
 def test_dead_worker_bookkeeping_uses_reported_files_not_file_existence(tmp_path, monkeypatch):

@@ -98,6 +98,107 @@ def test_wrong_group_and_truncated_files_are_declined_never_guessed(tmp_path):
     assert rc in (hostlib.OK, hostlib.UNSUPPORTED, hostlib.E_READ)
 
 
+def _member(data, name):
+    """Offset of a version-1 compound member record `name` (name padded to 8, byte offset, 28 bytes of dimension fields,
+    then the member's datatype: class/version, 3 flag bytes, size)."""
+    key = name + b"\x00" * (8 - len(name) % 8 if len(name) % 8 else 8)
+    i = data.find(key)
+    assert i > 0 and data.find(key, i + 1) < 0, name
+    return i + len(key)
+
+
+def test_compound_datatype_from_the_file_is_checked_not_trusted(tmp_path):
+    """member offsets and sizes of the Events compound come from the file.  A field outside its row,
+    an integer wider than 8 bytes or of an odd width, a row of no bytes: each is DECLINED (the Python stage then words
+    the error), never read out of bounds.  The mutations run in this process: a crash would end the test session loudly."""
+    data = open(FAST5[0], "rb").read()
+    rt, fq = _python_path(FAST5[0])
+    t = tmp_path / "mut.fast5"
+
+    def load(mut):
+        t.write_bytes(bytes(mut))
+        return hostlib.load_fast5(str(t), G, SG, True)
+
+    rc, o = load(bytearray(data))
+    assert rc == hostlib.OK and _same(o, rt, fq)
+    mv, st, ms, mean = (_member(data, n) for n in (b"move", b"start", b"model_state", b"mean"))
+    esize = int.from_bytes(data[mean - 8 - 4:mean - 8], "little")             # the compound's size: in front of its first member
+    assert esize == 41 and int.from_bytes(data[mv:mv + 4], "little") == 29, esize   # mean start stdv length model_state MOVE p_model_state weights
+    cases = []
+    for off in (0x7FFFFF00, 0xFFFFFFF0, esize - 3, esize):                       # the field leaves its row
+        m = bytearray(data); m[mv:mv + 4] = off.to_bytes(4, "little"); cases.append(("move offset %#x" % off, m))
+    for size in (64, 16, 9, 3, 0, 0x80000000):                                  # not an integer load_int can hold
+        m = bytearray(data); m[mv + 32 + 4:mv + 32 + 8] = size.to_bytes(4, "little"); cases.append(("move size %d" % size, m))
+        m = bytearray(data); m[st + 32 + 4:st + 32 + 8] = size.to_bytes(4, "little"); cases.append(("start size %d" % size, m))
+    m = bytearray(data); m[ms:ms + 4] = (esize - 2).to_bytes(4, "little"); cases.append(("model_state runs out of the row", m))
+    for es in (0, 1, 8):                                                         # rows shorter than their fields, or of no bytes
+        m = bytearray(data); m[mean - 12:mean - 8] = es.to_bytes(4, "little"); cases.append(("row of %d bytes" % es, m))
+    for what, m in cases:
+        rc, o = load(m)
+        assert rc == hostlib.UNSUPPORTED, (what, rc)
+    # a field moved to another place INSIDE the row is not an error the reader can see: it must simply not crash
+    m = bytearray(data); m[mv:mv + 4] = (0).to_bytes(4, "little")
+    assert load(m)[0] in (hostlib.OK, hostlib.UNSUPPORTED, hostlib.E_READ)
+
+
+def test_byte_flip_fuzz_many_seeds_in_a_child_process(tmp_path):
+    """Random corruption of the metadata region and of whole-file positions, 60 seeds x 2 files: every outcome is a return
+    code.  Run in a CHILD so that a crash of the native reader is this test's failure, not the end of the session."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from nanoreviser_amd import hostlib\n"
+        "n = 0\n"
+        "for path in %r:\n"
+        "    data = open(path, 'rb').read()\n"
+        "    for seed in range(60):\n"
+        "        rng = np.random.default_rng(seed)\n"
+        "        m = bytearray(data)\n"
+        "        hi = 4096 if seed %% 3 else len(data)\n"
+        "        for pos in rng.integers(8, hi, int(rng.integers(1, 32))):\n"
+        "            m[int(pos)] = int(rng.integers(0, 256)) if seed %% 2 else m[int(pos)] ^ 0xFF\n"
+        "        if seed %% 5 == 0:\n"                                          # and the datatype region in particular
+        "            i = data.find(b'model_state')\n"
+        "            for pos in rng.integers(i - 300, i + 300, 6):\n"
+        "                m[int(pos)] = int(rng.integers(0, 256))\n"
+        "        open(%r, 'wb').write(bytes(m))\n"
+        "        rc, o = hostlib.load_fast5(%r, %r, %r, True)\n"
+        "        assert rc in (hostlib.OK, hostlib.UNSUPPORTED, hostlib.E_READ, hostlib.E_IO), rc\n"
+        "        n += 1\n"
+        "print('fuzzed', n)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), FAST5, str(tmp_path / "f.fast5"), str(tmp_path / "f.fast5"), G, SG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzzed 120" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-2000:])
+
+
+def test_two_reads_with_one_destination_never_share_a_temporary(tmp_path):
+    """`a.x.fast5` and `a.y.fast5` both map to `a_out.fasta`; finisher THREADS of one process must not
+    write through one temporary.  32 threads x 40 writes to one destination: the file is always one whole record."""
+    from concurrent.futures import ThreadPoolExecutor
+    dst = str(tmp_path / "a_out.fasta")
+    rng = np.random.default_rng(1)
+    recs = []
+    for k in range(8):
+        n = 2000 + 300 * k
+        bases = np.array(list("ACGT"), dtype="S1")[rng.integers(0, 4, n + 12)]
+        recs.append((bases, np.full(n, 5 - (k % 4), np.int8), np.full(n, 4 - (k % 4), np.int8), f"read{k}"))
+    want = set()
+    for b, a1, a2, nm in recs:
+        hostlib.finish_read(b, a1, a2, 11, None, nm, dst, False)
+        want.add(open(dst, "rb").read())
+
+    def work(i):
+        b, a1, a2, nm = recs[i % 8]
+        return hostlib.finish_read(b, a1, a2, 11, None, nm, dst, False)
+    with ThreadPoolExecutor(32) as ex:
+        res = list(ex.map(work, range(32 * 40)))
+    assert all(r is not None and r > 0 for r in res)
+    assert open(dst, "rb").read() in want
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+
+
 class _Spec:
     def __init__(self, d, fmt):
         self.output_dir, self.output_format = d, fmt
