@@ -31,7 +31,9 @@ Besides the contract keys the line carries (N = 1, rank 0; --no-extras turns the
                       priming, warm-up, K timed steps, every-8th bracket, untimed all-kernel pass
   host_inclusive      nrv_predict / nrv_predict_read / nrv_predict_reads_raw from HOST memory
                       (H2D + D2H inside the timed call) - never `value`; cli_e2e: the command line itself,
-                      fast5 files in, FASTA files out, in a child process (NanoReviser.py:105-183)
+                      fast5 files in, FASTA files out, in a child process (NanoReviser.py:105-183).
+                      With --gpus N > 1 the line carries host_inclusive.cli_e2e with n_gpus = N
+                      (`NanoReviser.py --gpus N` on N times the files, run while the ranks wait)
   read_mode           config C5: one 200 k-event read, human weights, device-formed windows
   configs             C2 (ecoli, batch 512) and C3 (human, batch 4096) on the replicated fixture reads
   cpu_baseline        oracle/nrv_oracle.c (plain-C f32 port of the reference graph - test
@@ -283,7 +285,7 @@ def host_stage_us_per_base():
                               "container (SURVEY.md 6); /root/reference does not exist on the GPU box"}
 
 
-def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
+def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0, host_cap=None):
     """oracle/nrv_oracle.c on all host cores (bounded to ~target_s) and on one thread (~target_s/2)."""
     from oracle import c_oracle as CO
     cores, aff, quota = host_cores()
@@ -327,7 +329,7 @@ def cpu_baseline(m1, m2, T, sig, rd, target_s=12.0):
             "affinity": {"mask": _mask_str(aff), "n": len(aff), "os_cpu_count": os.cpu_count(),
                          "cgroup_cpu_quota": quota},
             "blas_grade": blas,
-            "host_capacity": host_capacity(cores),
+            "host_capacity": host_cap if host_cap is not None else {"error": "not measured (no helper process)"},
             "host_stage_us_per_base": host_stage_us_per_base(),
             "reference_keras_tf": ref,
             "note": "kind 'port': the reference's path is Python on keras 2.2.4 / tensorflow 1.12, which cannot be "
@@ -353,6 +355,23 @@ def kernel_source_sha(precision):
     hsh = hashlib.sha256()
     for f in KERNEL_SOURCES[precision]:
         with open(os.path.join(ROOT, "nanoreviser_amd", "csrc", f), "r") as fp:
+            for line in fp:
+                code = re.sub(r"\s*//.*$", "", line.rstrip("\n")).rstrip()
+                if code:
+                    hsh.update(code.encode() + b"\n")
+    return hsh.hexdigest()[:16]
+
+
+def step_source_sha():
+    """sha256 of every kernel source of the step (csrc/*.h + nrv_api.hip, comments and blank lines excluded): the
+    step-wide PMC figures (`traffic_step`) describe the library only while none of them has changed."""
+    import glob
+    import hashlib
+    import re
+    hsh = hashlib.sha256()
+    csrc = os.path.join(ROOT, "nanoreviser_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "nrv_*.h"))) + [os.path.join(csrc, "nrv_api.hip")]:
+        with open(f, "r") as fp:
             for line in fp:
                 code = re.sub(r"\s*//.*$", "", line.rstrip("\n")).rstrip()
                 if code:
@@ -388,50 +407,136 @@ class NullEngine:
         pass
 
 
-def host_capacity(cores, reps=400):
-    """bases/s through `cli.process_files` with a NullEngine on the two committed fixture reads x reps, at 1, 4 and 16
-    parser workers (capped at the cores this process may use): how many bases per second the host stage delivers."""
+def _hostcap_files(tmp, n_reads):
+    """n_reads hard links (copies where links are refused) of the committed fixture fast5 files -> (dir, names)."""
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "fast5")
+    src = sorted(f for f in os.listdir(gold) if f.endswith(".fast5"))
+    if not src:
+        raise RuntimeError("no fixture fast5 files")
+    din = os.path.join(tmp, "in")
+    os.makedirs(din, exist_ok=True)
+    names = []
+    for i in range(n_reads):
+        fn = f"r{i:06d}_{i % len(src)}.fast5"
+        dst = os.path.join(din, fn)
+        if not os.path.exists(dst):
+            try:
+                os.link(os.path.join(gold, src[i % len(src)]), dst)
+            except OSError:
+                shutil.copy(os.path.join(gold, src[i % len(src)]), dst)
+        names.append(fn)
+    return din, names
+
+
+def _hostcap_worker(rank, world, din, names, out_dir, threads, barrier, q):
+    """One simulated GPU worker of `host_capacity`'s N-worker point: the command line's own worker body
+    (cli.process_files with gpu_workers = world) around an engine that computes nothing."""
+    try:
+        from nanoreviser_amd import cli
+        args = cli.get_args(["-d", din + "/", "-o", out_dir + "/", "-S", "ecoli", "--thread", str(threads)])
+        os.makedirs(args.output_dir, exist_ok=True)
+        cpus = cli.worker_cpus(rank, world, [0] * world)
+        share = None
+        if cpus:
+            cores_all = cli.usable_cores()
+            os.sched_setaffinity(0, cpus)
+            share = max(1, min(len(cpus), cores_all // world))
+        cli.process_files(args, names[:8], NullEngine(), lambda m: None, gpu_workers=world, core_share=share)   # warm
+        barrier.wait(120)
+        st = cli.process_files(args, names, NullEngine(), lambda m: None, gpu_workers=world, core_share=share)
+        q.put((rank, st["bases"], st["parser_workers"], None))
+    except BaseException as e:
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        q.put((rank, 0, 0, repr(e)))
+
+
+def host_capacity(cores, min_s=2.0, max_reads=24000):
+    """bases/s through `cli.process_files` with a NullEngine: how many bases per second this host can FEED to GPUs.
+    Runs in the helper child (`bench.py --helper`): a fresh process with no OpenMP / torch thread pools alive (the
+    r04 figure was taken right behind a 16-thread OpenMP leg and a 16-thread torch leg on a 16-core quota, with a
+    57 ms sample: the driver saw 27.6 M where other boxes print 95 M).  Every point is a calibration pass followed
+    by ONE timed pass over enough reads for >= min_s seconds (at most max_reads):
+      workers_1 / workers_4 / workers_<cores>   parser threads of one GPU worker, cap lifted (what w threads deliver)
+      cli_1gpu                                  the pool the command line really runs for one GPU (cli.kNativePoolMax)
+      cli_8gpu_workers                          8 worker PROCESSES as `NanoReviser.py --gpus 8` starts them, each with
+                                                its share of the cores (cli.parser_pool_size) and its NUMA pinning"""
+    import multiprocessing as mp
     import shutil
     import tempfile
     from nanoreviser_amd import cli
-    src = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden", "fast5")) if f.endswith(".fast5"))
-    if not src:
-        return {"error": "no fixture fast5 files"}
     tmp = tempfile.mkdtemp(prefix="nrv_hostcap_")
+    per_read = 6800.0                                    # bases per fixture read, refined by the calibration pass
+    out = {"unit": "bases/s", "min_sample_s": min_s,
+           "what": "cli.process_files with an engine that computes nothing: fast5 parse, event collapse, statistics, packing, "
+                   "merge, FASTA write of the committed fixture reads (hard links); fresh child process, one timed pass per point"}
     try:
-        din = os.path.join(tmp, "in")
-        os.makedirs(din)
-        names = []
-        for i in range(reps):
-            for j, f in enumerate(src):
-                fn = f"r{i:04d}_{j}.fast5"
-                try:
-                    os.link(os.path.join(ROOT, "tests", "golden", "fast5", f), os.path.join(din, fn))
-                except OSError:
-                    shutil.copy(os.path.join(ROOT, "tests", "golden", "fast5", f), os.path.join(din, fn))
-                names.append(fn)
-        out = {"unit": "bases/s", "reads": len(names),
-               "what": "cli.process_files with an engine that computes nothing: fast5 parse, event collapse, statistics, "
-                       "packing, merge, FASTA write of the two committed fixture reads x %d" % reps}
-        for w in [-min(16, cores)] + sorted({1, min(4, cores), min(16, cores)}):
-            args = cli.get_args(["-d", din + "/", "-o", os.path.join(tmp, f"out{w}") + "/", "-S", "ecoli", "--thread", str(abs(w))])
-            os.makedirs(args.output_dir, exist_ok=True)
-            if w < 0:       # untimed: the pool threads' first calls pay for their malloc arenas and the page cache
-                cli.process_files(args, names[:min(len(names), 40 * abs(w))], NullEngine(), lambda m: None)
-                continue
-            t0 = time.perf_counter()
-            cap, cli.kNativePoolMax = cli.kNativePoolMax, 64      # this leg measures what w workers deliver: no cap
+        def one(tag, threads, cap):
+            nonlocal per_read
+            keep = cli.kNativePoolMax
+            os.environ.pop("NRV_PARSER_THREADS_MAX", None)
+            cli.kNativePoolMax = cap
             try:
+                odir = os.path.join(tmp, "out_" + tag)
+                args = cli.get_args(["-d", os.path.join(tmp, "in") + "/", "-o", odir + "/", "-S", "ecoli", "--thread", str(threads)])
+                os.makedirs(odir, exist_ok=True)
+                n_cal = 200 * max(1, min(threads, cap))
+                din, names = _hostcap_files(tmp, n_cal)
+                t0 = time.perf_counter()
                 st = cli.process_files(args, names, NullEngine(), lambda m: None)
+                dt = time.perf_counter() - t0
+                per_read = st["bases"] / max(st["reads"], 1)
+                n = int(min(max_reads, max(n_cal, 1.25 * min_s * st["reads"] / max(dt, 1e-3))))
+                din, names = _hostcap_files(tmp, n)
+                t0 = time.perf_counter()
+                st = cli.process_files(args, names, NullEngine(), lambda m: None)
+                dt = time.perf_counter() - t0
+                out[tag] = st["bases"] / dt
+                out[tag + "_detail"] = {"reads": st["reads"], "seconds": dt, "parser_threads": st["parser_workers"],
+                                        "host_ms_per_read": st["host_s"] / max(st["reads"], 1) * 1e3}
+                out["host_stage"] = st.get("host_stage")
+                shutil.rmtree(odir, ignore_errors=True)
             finally:
-                cli.kNativePoolMax = cap
+                cli.kNativePoolMax = keep
+        for w in sorted({1, min(4, cores), cores}):
+            one(f"workers_{w}", w, 64)
+        one("cli_1gpu", cores, cli.kNativePoolMax)
+        # ---- eight GPU workers, as processes
+        world = 8
+        rate1 = out.get(f"workers_{cores}", 2e7)
+        n = int(min(max_reads, max(800, 1.25 * min_s * rate1 / per_read)))
+        din, names = _hostcap_files(tmp, n)
+        ctx = mp.get_context("spawn")
+        barrier, q = ctx.Barrier(world + 1), ctx.Queue()
+        procs = [ctx.Process(target=_hostcap_worker, args=(r, world, din, names[r::world], os.path.join(tmp, f"out8_{r}"), cores, barrier, q))
+                 for r in range(world)]
+        for pr in procs:
+            pr.start()
+        try:
+            barrier.wait(180)
+            t0 = time.perf_counter()
+            res = [q.get(timeout=300) for _ in procs]
             dt = time.perf_counter() - t0
-            out[f"workers_{w}"] = st["bases"] / dt
-            out["host_stage"] = st.get("host_stage")
-            out[f"host_ms_per_read_workers_{w}"] = st["host_s"] / max(st["reads"], 1) * 1e3
+            errs = [e for _, _, _, e in res if e]
+            if errs:
+                out["cli_8gpu_workers"] = {"error": errs[0]}
+            else:
+                out["cli_8gpu_workers"] = sum(b for _, b, _, _ in res) / dt
+                out["cli_8gpu_workers_detail"] = {"reads": n, "seconds": dt, "worker_processes": world,
+                                                  "parser_threads_per_worker": sorted({t for _, _, t, _ in res})}
+        except Exception as e:
+            out["cli_8gpu_workers"] = {"error": repr(e)}
+        for pr in procs:
+            pr.join(30)
+            if pr.is_alive():
+                pr.terminate()
         return out
     except Exception as e:
-        return {"error": repr(e)}
+        out["error"] = repr(e)
+        return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -491,8 +596,8 @@ def load_traffic(T, batch, precision, profiles_dir=None):
         if "kernel_name" not in j or "source_sha256_16" not in j:
             why = f"{name} carries no kernel name / source hash (rounds 1-3): not trusted for the current kernel"
             continue
-        return j.get("hbm_bytes_per_launch"), f"{name} @ {j.get('commit', '?')}: {j.get('source', '')}"
-    return None, why
+        return j.get("hbm_bytes_per_launch"), f"{name} @ {j.get('commit', '?')}: {j.get('source', '')}", j
+    return None, why, {}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -562,7 +667,8 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_h
     out["host_inclusive"] = hi
     rv.close()
     if cli_helper is not None:                               # the command line itself, in a process of its own
-        hi["cli_e2e"] = cli_helper.run()
+        cores, _, _ = host_cores()
+        hi["cli_e2e"] = cli_helper.ask({"cmd": "cli", "reps": args.cli_reps, "threads": min(cores, 16), "gpus": 1})
 
     # ---- C5: one long read, human weights, streamed in device-formed window groups
     h1, h2 = load_species("human")
@@ -717,6 +823,22 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
         "executed_tflops": ach * PRODUCTS[precision],
         "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
     }
+    # north_star: "rocprof HBM GB/s and MFMA utilisation reported against gfx950 peak" - from the committed PMC pass of this
+    # kernel (null, with the reason in traffic_source, when that pass no longer describes the kernel)
+    tr, _, rec = load_traffic(T, B, precision)
+    r = out["roofline" + suffix]
+    r["hbm_gbps"] = tr / avg_s / 1e9 if tr else None
+    r["hbm_frac_of_peak"] = tr / avg_s / 8e12 if tr else None
+    r["mfma_busy_frac"] = rec.get("mfma_busy_frac")
+    r["mfma_busy_note"] = rec.get("mfma_busy_note")
+    step_ok = rec.get("step_source_sha256_16") == step_source_sha() if rec.get("traffic_step") else False
+    r["traffic_step"] = rec.get("traffic_step") if step_ok else None
+    r["traffic_step_by_kernel"] = rec.get("traffic_step_by_kernel") if step_ok else None
+    if rec.get("traffic_step") and not step_ok:
+        r["traffic_step_note"] = "the committed PMC pass was collected on another version of the step's kernels: not printed"
+    elif step_ok:
+        r["traffic_step_note"] = (f"HBM-side bytes of all launches of one {B}-window step (PMC, FETCH_SIZE x2 + WRITE_SIZE) against "
+                                  f"{B * (T * 56 * 4 + 11 * 4 + 2)} algorithmic bytes in / out")
     if precision == "f16x2":
         # measured, not assumed (profiles/r04_clock_vs_fill.txt, profiles/r04_power_by_launch.json)
         out["roofline" + suffix]["power_note"] = (
@@ -736,50 +858,94 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
     return out
 
 
-class CliHelper:
-    """End-to-end figure of the command line (fast5 in, FASTA out: NanoReviser.py:105-183) for the JSON line.
-    The CLI must run in a process of its own, and a process that has initialised the GPU must not exec
-    another program: so a helper child (`bench.py --cli-e2e-helper`, which never touches a GPU itself) is
-    started BEFORE this process makes its first HIP call, waits on its stdin, and on "go" runs
-    `python NanoReviser.py` on the two committed fixture reads x REP as ITS child, timing it from outside."""
+class Helper:
+    """A child of rank 0 that never touches a GPU, started BEFORE this process makes its first HIP call (a process that
+    has initialised the GPU must not exec another program; a plain child that was forked off earlier may start whatever
+    it likes).  It takes one JSON command per line on stdin and answers with one JSON line:
+      {"cmd": "cli", "gpus": N, ...}   the command line itself, fast5 files in, FASTA files out, N GPU workers, as ITS
+                                       child process, timed from outside (NanoReviser.py:105-183, 203-219)
+      {"cmd": "hostcap", "cores": C}   `host_capacity` in this fresh process (no OpenMP / torch pools alive)"""
 
-    def __init__(self, reps, threads):
-        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cli-e2e-helper",
-                                   "--cli-reps", str(reps), "--cli-threads", str(threads)],
-                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    def __init__(self):
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--helper"],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
 
-    def run(self):
-        try:
-            out, _ = self.p.communicate("go\n", timeout=600)
-            return json.loads(out.strip().splitlines()[-1])
-        except Exception as e:
-            self.close()
-            return {"error": repr(e)}
+    def ask(self, cmd, timeout=900):
+        import threading
+        box = {}
+
+        def talk():
+            try:
+                self.p.stdin.write(json.dumps(cmd) + "\n")
+                self.p.stdin.flush()
+                while True:
+                    line = self.p.stdout.readline()
+                    if not line:
+                        box["r"] = {"error": "helper ended without an answer"}
+                        return
+                    if line.startswith("{"):
+                        box["r"] = json.loads(line)
+                        return
+            except Exception as e:
+                box["r"] = {"error": repr(e)}
+        t = threading.Thread(target=talk, daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            self.p.kill()
+            return {"error": f"helper did not answer {cmd.get('cmd')} within {timeout} s"}
+        return box.get("r", {"error": "no answer"})
 
     def close(self):
         if self.p.poll() is None:
             try:
-                self.p.communicate("quit\n", timeout=10)
+                self.p.communicate(json.dumps({"cmd": "quit"}) + "\n", timeout=10)
             except Exception:
                 self.p.kill()
 
 
-def cli_e2e_helper(reps, threads):
+def helper_main():
     """Body of the helper child (no GPU call in this process, ever)."""
+    for line in sys.stdin:
+        try:
+            cmd = json.loads(line)
+        except ValueError:
+            continue
+        if cmd.get("cmd") == "quit":
+            break
+        try:
+            if cmd.get("cmd") == "cli":
+                res = cli_e2e(cmd.get("reps", 2000), cmd.get("threads", 16), cmd.get("gpus", 1), cmd.get("share", False))
+            elif cmd.get("cmd") == "hostcap":
+                res = host_capacity(int(cmd.get("cores", 1)), float(cmd.get("min_s", 2.0)))
+            else:
+                res = {"error": f"unknown command {cmd.get('cmd')!r}"}
+        except Exception as e:
+            res = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    return 0
+
+
+def cli_e2e(reps, threads, gpus=1, share=False):
+    """`python NanoReviser.py --gpus N` on the committed fixture reads x reps x N (weak scaling: the file set grows with
+    the GPUs), as a child process of the helper, wall time from outside, start-up included."""
     import glob
     import shutil
     import tempfile
-    if sys.stdin.readline().strip() != "go":
-        return 0
     src = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fast5", "*.fast5")))
     work = tempfile.mkdtemp(prefix="nrv_cli_e2e_")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NRV_BENCH_CHILD"):
+        env.pop(k, None)                                     # the command line is not a rank of this job
+    if share:
+        env["NRV_SHARE_DEVICE"] = "1"
     try:
         din, dout = os.path.join(work, "in"), os.path.join(work, "out") + "/"
         os.makedirs(din)
         for i, f in enumerate(src):
-            for k in range(reps):
+            for k in range(reps * gpus):
                 os.symlink(f, os.path.join(din, f"r{i}_{k}.fast5"))
-        res = {"reads": len(src) * reps, "threads": threads}
+        res = {"reads": len(src) * reps * gpus, "threads": threads, "n_gpus": gpus, "share_device": bool(share)}
         for name, n in (("start_up", 2), ("run", None)):     # two reads first: what a run costs before it streams
             if n is not None:
                 d2 = os.path.join(work, "in2")
@@ -789,8 +955,8 @@ def cli_e2e_helper(reps, threads):
                         os.symlink(os.path.realpath(os.path.join(din, f)), os.path.join(d2, f))
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, os.path.join(ROOT, "NanoReviser.py"), "-d", din if n is None else d2,
-                                "-o", dout, "-S", "ecoli", "--thread", str(threads), "--gpus", "1"],
-                               capture_output=True, text=True, timeout=500)
+                                "-o", dout, "-S", "ecoli", "--thread", str(threads), "--gpus", str(gpus if n is None else 1)],
+                               capture_output=True, text=True, timeout=800, env=env)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 res["error"] = f"{name}: rc {r.returncode}: {r.stderr[-300:]}"
@@ -803,13 +969,13 @@ def cli_e2e_helper(reps, threads):
                 res.update({"wall_s": dt, "bases": nb, "bases_per_s": nb / dt,
                             "files_written": len([f for f in os.listdir(dout) if f.endswith("_out.fasta")]),
                             "cli_report": line[-1].strip() if line else None})
-        res["what"] = (f"python NanoReviser.py -d <{len(src)} committed fixture fast5 x {reps}, symlinked> -o <tmp> -S ecoli "
-                       f"--thread {threads} --gpus 1: own HDF5 reader, event collapse, device-side segmentation, "
-                       "model1+model2, merge, one FASTA per read; wall time of the child process, start-up included")
-        print(json.dumps(res), flush=True)
+        res["what"] = (f"python NanoReviser.py -d <{len(src)} committed fixture fast5 x {reps * gpus}, symlinked> -o <tmp> -S ecoli "
+                       f"--thread {threads} --gpus {gpus}: own HDF5 reader, event collapse, device-side segmentation, "
+                       "model1+model2, merge, one FASTA per read; wall time of the child process, start-up included"
+                       + ("; NRV_SHARE_DEVICE=1: the workers share the devices there are (rehearsal)" if share else ""))
+        return res
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    return 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -849,9 +1015,8 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     # the CLI helper must exist before this process makes its first HIP call (see CliHelper)
     cli_helper = None
-    if rank == 0 and args.gpus == 1 and not args.no_extras and not args.no_cli_e2e:
-        cores, _, _ = host_cores()
-        cli_helper = CliHelper(args.cli_reps, min(cores, 16))
+    if rank == 0 and not args.no_extras and not (args.no_cli_e2e and args.no_cpu_baseline):
+        cli_helper = Helper()
     import torch
     from nanoreviser_amd.engine import Reviser
     from nanoreviser_amd.weights import load_species
@@ -950,7 +1115,7 @@ def run_rank(args):
     if d.rank == 0 and args.gpus == 1 and not args.no_extras:
         del d_sig, d_rd
         try:
-            out.update(extras(args, torch, dev, device, m1, m2, sig, rd, ms_per_step, cli_helper))
+            out.update(extras(args, torch, dev, device, m1, m2, sig, rd, ms_per_step, None if args.no_cli_e2e else cli_helper))
             # the reference-precision figure next to `value` (same protocol, same run): nobody should have to dig for it
             if "roofline_f32" in out:
                 out["value_f32"] = out["roofline_f32"]["bases_per_s"]
@@ -958,10 +1123,26 @@ def run_rank(args):
                 out["dtype_f32"] = DTYPE["f32"]
         except Exception as e:                               # never lose the main line to a secondary block
             out["extras_error"] = repr(e)
+    if args.gpus > 1 and not args.no_extras and not args.no_cli_e2e:
+        # The metric as BASELINE.json words it - fast5 files in, revised reads out, whole node: the command line with N GPU
+        # workers (NanoReviser.py:203-219 fans out the same way) on the fixture reads x cli_reps x N, as a child of rank 0's
+        # helper, while every rank of THIS job sits in the barrier with its engine closed (the GPUs are the CLI's).
+        d.barrier()
+        if d.rank == 0 and cli_helper is not None:
+            cores, _, _ = host_cores()
+            out["host_inclusive"] = {"cli_e2e": cli_helper.ask({"cmd": "cli", "reps": args.cli_reps, "threads": min(cores, 16),
+                                                                "gpus": args.gpus, "share": bool(args.share_device)})}
+            v = out["host_inclusive"]["cli_e2e"].get("bases_per_s")
+            if v:
+                out["value_cli_e2e"] = v
+        d.barrier()
+    host_cap = None
+    if d.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and cli_helper is not None:
+        host_cap = cli_helper.ask({"cmd": "hostcap", "cores": host_cores()[0], "min_s": args.hostcap_seconds})
     if cli_helper is not None:
         cli_helper.close()
     if d.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(m1, m2, T, sig, rd)
+        out["cpu_baseline"] = cpu_baseline(m1, m2, T, sig, rd, host_cap=host_cap)
     if d.rank == 0:
         print(json.dumps(out), flush=True)
     d.close()
@@ -991,12 +1172,12 @@ def main(argv=None):
                     help="rank r runs on device r %% device_count (rehearse N ranks on fewer GPUs; never the default)")
     ap.add_argument("--no-cli-e2e", action="store_true", help="skip host_inclusive.cli_e2e (the CLI in a child process)")
     ap.add_argument("--cli-reps", type=int, default=2000, help="cli_e2e: copies of each committed fixture read")
-    ap.add_argument("--cli-threads", type=int, default=16, help=argparse.SUPPRESS)
-    ap.add_argument("--cli-e2e-helper", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--hostcap-seconds", type=float, default=2.0, help="cpu_baseline.host_capacity: seconds per point")
+    ap.add_argument("--helper", action="store_true", help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
-    if args.cli_e2e_helper:
-        return cli_e2e_helper(args.cli_reps, args.cli_threads)
+    if args.helper:
+        return helper_main()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

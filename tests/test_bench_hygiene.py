@@ -22,21 +22,44 @@ def _pmc(tmp_path, **over):
 
 
 def test_traffic_is_printed_only_for_the_kernel_it_was_measured_on(tmp_path):
-    v, src = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path))
+    v, src, _ = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path))
     assert v == 2.8e8 and "r99_pmc_lstm3.json @ abc1234" in src
-    v, src = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, source_sha256_16="0" * 16))
+    v, src, _ = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, source_sha256_16="0" * 16))
     assert v is None and "stale" in src                                   # the kernel's source changed since
-    v, src = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, kernel_name="void nrv::lstm_h2o_kernel<32, 16, 128>"))
+    v, src, _ = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, kernel_name="void nrv::lstm_h2o_kernel<32, 16, 128>"))
     assert v is None and "another kernel" in src
     rec = json.loads((tmp_path / "r99_pmc_lstm3.json").read_text())["f16x2"]
     del rec["kernel_name"]
     (tmp_path / "r99_pmc_lstm3.json").write_text(json.dumps({"f16x2": rec}))
-    v, src = bench.load_traffic(13, 4096, "f16x2", str(tmp_path))
+    v, src, _ = bench.load_traffic(13, 4096, "f16x2", str(tmp_path))
     assert v is None and "not trusted" in src                             # a file of rounds 1-3: no kernel name
     assert bench.load_traffic(11, 4096, "f16x2", str(tmp_path))[0] is None   # another shape
+    # the step-wide figure and the MFMA utilisation travel in the same record
+    _, _, rec = bench.load_traffic(13, 4096, "f16x2", _pmc(tmp_path, mfma_busy_frac=0.67, traffic_step=7.6e8,
+                                                           step_source_sha256_16=bench.step_source_sha()))
+    assert rec["mfma_busy_frac"] == 0.67 and rec["step_source_sha256_16"] == bench.step_source_sha()
     # whatever is committed under profiles/ either matches the current kernel or is refused with a reason
-    v, src = bench.load_traffic(13, 4096, "f16x2")
+    v, src, _ = bench.load_traffic(13, 4096, "f16x2")
     assert (v is None) == (not src.startswith("profiles/r")) or "@" not in src
+
+
+def test_helper_child_answers_json_commands_and_never_imports_torch():
+    """bench.py's helper (a child of rank 0 started before the first HIP call): one JSON answer per JSON command; the
+    host-capacity leg runs INSIDE it, so it must stay free of torch / OpenMP pools."""
+    h = bench.Helper()
+    try:
+        assert "unknown command" in h.ask({"cmd": "nope"}, timeout=60)["error"]
+        r = h.ask({"cmd": "hostcap", "cores": 2, "min_s": 0.05}, timeout=300)
+        assert "error" not in r, r
+        for k in ("workers_1", "workers_2", "cli_1gpu", "cli_8gpu_workers"):
+            assert isinstance(r[k], float) and r[k] > 0, (k, r)
+        assert r["cli_8gpu_workers_detail"]["worker_processes"] == 8 and r["host_stage"].startswith("native")
+    finally:
+        h.close()
+    assert h.p.wait(20) == 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def helper_main():"):src.index("def cli_e2e(")]
+    assert "torch" not in body
 
 
 def test_kernel_signatures_are_what_the_library_launches():
