@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 using namespace nrv;
@@ -1127,8 +1128,13 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       }
       dim3 grid((n + 63) / 64, 2, 2);
       if (!NRV_RUN_STAGE(2)) {}
+#if NRV_L2_PAIR          // two waves per chain (nrv_lstm2_u.h, r05); 0: one wave per chain (nrv_lstm2_t.h) - bit-identical
+      else if (h->act == 0) hipLaunchKernelGGL(lstm2_u_kernel<0>, grid, dim3(kL2uThreads), 0, h->stream, ta);
+      NRV_ACT1(else hipLaunchKernelGGL(lstm2_u_kernel<1>, grid, dim3(kL2uThreads), 0, h->stream, ta);)
+#else
       else if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
       NRV_ACT1(else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);)
+#endif
     }
     else if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
@@ -1526,6 +1532,7 @@ struct HostPin {
     on = true;
     return true;
   }
+  void release() { this->~HostPin(); on = false; }
   ~HostPin() {
     if (!on) return;
     if (!settled) {                             // error paths: no DMA of THIS handle may still be reading the range
@@ -1571,9 +1578,14 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   const int64_t n = read_mode ? n_in - T : n_in;
   if (n <= 0) return NRV_OK;
   const size_t ev_all = read_mode ? (size_t)n_in : (size_t)n_in * T;
+  // NRV_HOST_TRACE=1: where a host-pointer call's wall time goes (registration, pipeline, drain, unregistration), to stderr
+  static const bool trace = getenv("NRV_HOST_TRACE") && atoi(getenv("NRV_HOST_TRACE")) > 0;
+  const auto t_0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   HostPin pin_s, pin_f;
   const bool direct_s = !raw_reads && pin_s.pin(h, sig, ev_all * kSig * 4);
   const bool direct_f = pin_f.pin(h, feat, ev_all * kFeat * 4);
+  const double ms_reg = since(t_0);
   // a pipeline stage = one upload, its launch groups (on the lanes when groups are small), one download
   const int stage = stage_windows(h, read_mode);
   const size_t ev_grp = read_mode ? (size_t)(stage + T - 1) : (size_t)stage * T;
@@ -1666,6 +1678,13 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   HIPCHK(h, hipStreamSynchronize(h->d2h_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   pin_s.settled = pin_f.settled = true;
+  if (trace) {
+    const double ms_run = since(t_0) - ms_reg;
+    const auto t_u = std::chrono::steady_clock::now();
+    pin_s.release(); pin_f.release();
+    fprintf(stderr, "[nrv host trace] %lld windows, %d stages: register %.3f ms (sig %d, feat %d), pipeline %.3f ms, unregister %.3f ms\n",
+            (long long)n, (int)g, ms_reg, (int)direct_s, (int)direct_f, ms_run, since(t_u));
+  }
   return NRV_OK;
 }
 

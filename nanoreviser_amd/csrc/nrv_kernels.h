@@ -41,6 +41,10 @@
 #include "nrv_lstm_f16x2s.h"   // lstm_h2s_kernel (256->64 layer of the f16x2 mode, 16x16x32 tiles; 192->128 with -DNRV_L3_WS=0)
 #include "nrv_lstm_f16x2w.h"   // lstm_h2w_kernel (192->128 layer: eight waves, two groups running a step in opposite order)
 #include "nrv_lstm2_t.h"       // lstm2_t_kernel (32->64 layer: transposed products, wave-private recurrence)
+#ifndef NRV_L2_PAIR
+#define NRV_L2_PAIR 1
+#endif
+#include "nrv_lstm2_u.h"       // lstm2_u_kernel (the same with two waves per chain, h halves through LDS: r05)
 #include "nrv_cnn_r.h"         // cnn_r_kernel (signal branch of the f16x2 mode: conv1 -> conv2 -> dense in registers)
 #include "nrv_head.h"          // head_mlp_kernel, head_mlp_split_kernel, head_final_kernel
 #include "nrv_head_f16x2.h"    // head_h2_kernel (per-timestep MLP + per-window tail, f16x2 mode)
