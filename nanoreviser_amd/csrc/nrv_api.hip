@@ -471,6 +471,7 @@ struct DevModel {
   size_t l1s2, l1h2;
   size_t cr_dbias = 0;                   // cnn_r_kernel: dense bias x 2^16
   size_t cr_w2 = 0, cr_ep = 0, cr_d = 0; // cnn_r_kernel: conv2 in its two-position form, epilogue constants, dense A fragments
+  size_t cr_c1 = 0;                      // cnn_r_kernel: conv1 as a matrix product: per-lane A operand, bias, BatchNorm 1
   CnnRConsts cr_k;                       // ... and the first convolution's constants (kernel arguments)
   size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
   HeadH2Scales hsc;
@@ -522,6 +523,7 @@ struct nrv_handle {
   // points (downloaded with each stage's outputs), [2] = device-pointer calls (read by nrv_saturated)
   unsigned* d_sat = nullptr;
   unsigned* pin_sat[2] = {nullptr, nullptr};
+  unsigned sat_seen[2] = {0, 0};   // the staging sets' counters only grow: a stage fired iff its counter moved since the last look
   int64_t sat_reruns = 0;          // pipeline stages the host entry points re-ran on the f32 kernels
   int h2 = 1;                      // 1: f16x2 mode (the default) - lstm2..4 on lstm_h2o / lstm_h2s_kernel, activations between the kernels
                                    // as f16 split planes (cnn dense and head stay on their bf16x3 kernels)
@@ -689,6 +691,23 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
         d.cr_d = put(d2.data(), d2.size());
       }
       const float* c0 = host.data() + d.conv;                  // unscaled: w1 24, b1 8, s1 8, h1 8
+      {
+        // conv1 as v_mfma_f32_16x16x4_f32 (nrv_cnn_r.h, NRV_CNNR_C1MFMA): A[m][k] for lane (m = l & 15, k = l >> 4): rows 0-7
+        // channel m of position P (taps k = 0..2), rows 8-15 channel m - 8 of position P + 1 (taps k - 1); the result lane
+        // (n, q) holds rows 4 q .. + 3: channels (4 q + r) & 7 - its bias, BatchNorm 1 scale / shift x 2^6
+        float tab[64 * 16] = {0};
+        NRV_FOR (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, k = lane >> 4, co = m & 7, tap = m < 8 ? k : k - 1;
+          tab[lane * 16] = (tap >= 0 && tap < 3) ? c0[tap * 8 + co] : 0.f;
+          NRV_FOR (int r = 0; r < 4; ++r) {
+            const int ch = (4 * k + r) & 7;
+            tab[lane * 16 + 4 + r] = c0[24 + ch];
+            tab[lane * 16 + 8 + r] = std::ldexp(c0[32 + ch], 6);
+            tab[lane * 16 + 12 + r] = std::ldexp(c0[40 + ch], 6);
+          }
+        }
+        d.cr_c1 = put(tab, 64 * 16);
+      }
       memcpy(d.cr_k.w1, c0, 24 * 4);
       memcpy(d.cr_k.b1, c0 + 24, 8 * 4);
       NRV_FOR (int o = 0; o < 8; ++o) { d.cr_k.s1[o] = std::ldexp(c0[32 + o], 6); d.cr_k.h1[o] = std::ldexp(c0[40 + o], 6); }
@@ -1040,7 +1059,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       CnnRArgs a2;
       for (int m = 0; m < 2; ++m) {
         const DevModel& d = h->dm[m];
-        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.cr_dbias, h->S[m]};
+        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.cr_dbias, h->S[m], d.all + d.cr_c1};
         a2.k[m] = d.cr_k;
       }
       a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
@@ -1604,7 +1623,7 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     HIPCHK(h, hipEventSynchronize(h->ev_out[st]));
     char* o = h->pin_out[st];
     const size_t rows = (size_t)h->cap_rows;
-    if (*h->pin_sat[st] != 0) {
+    if (*h->pin_sat[st] != h->sat_seen[st]) {
       // f16x2 range guard: the signal branch of this stage left the f16 range (a spike sample, a tiny MAD, a
       // NaN).  Its inputs are still in staging set st (the set is reused two stages later): run the stage
       // again on the f32 kernels, which have no range limit, and take those results.
@@ -1618,7 +1637,7 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
       if (a1) HIPCHK(h, hipMemcpyAsync(o + rows * 44, h->d_a[st][0], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
       if (a2) HIPCHK(h, hipMemcpyAsync(o + rows * 45, h->d_a[st][1], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
-      *h->pin_sat[st] = 0;
+      h->sat_seen[st] = *h->pin_sat[st];
       h->sat_reruns += 1;
     }
     if (p1) memcpy(p1 + s * 6, o, (size_t)nb * 24);
@@ -1635,14 +1654,13 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
     const float* hs = raw_reads ? nullptr : sig + (read_mode ? s * kSig : s * T * kSig);
     const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
-    if (g >= 2) {
-      // staging set st was last used by group g-2: its upload has left the bounce buffers, its kernels
-      // have read d_sig / d_feat (ev_done) and its results have left d_p / d_a (ev_out)
-      if (!direct_s || !direct_f) HIPCHK(h, hipEventSynchronize(h->ev_in[st]));
-      HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_done[st], 0));
-      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_out[st], 0));
-    }
+    // Staging set st was last used by stage g-2.  Nothing has to be waited for here: the previous iteration ended with
+    // finalize(g-2) - a HOST wait for that stage's download (ev_out), which ran behind its kernels (ev_done), which ran behind
+    // its upload (ev_in) - so its bounce buffers, d_sig / d_feat and d_p / d_a are all free again.  (Until r05 three waits stood
+    // here, one of them a barrier packet on the compute stream per stage.)
     if (!raw_reads) {
+      // ONE copy per stage: two halves on two copy streams were measured (r05c: 3.40 vs 3.30 ms per 8-stage call) - a single
+      // stream already moves 53-57 GB/s (tools/microbench/h2d_rate.hip), whichever way the memory was page-locked
       const void* src = hs;
       if (!direct_s) { memcpy(h->pin_sig[st], hs, ev * kSig * 4); src = h->pin_sig[st]; }
       HIPCHK(h, hipMemcpyAsync(h->d_sig[st], src, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
@@ -1655,7 +1673,6 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     HIPCHK(h, hipEventRecord(h->ev_in[st], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[st], 0));
     if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[st]);
-    if (h->h2) HIPCHK(h, hipMemsetAsync(h->d_sat + st, 0, sizeof(unsigned), h->stream));   // this stage's range guard
     if ((rc = run_stage(nb, st))) return rc;
     HIPCHK(h, hipEventRecord(h->ev_done[st], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, h->ev_done[st], 0));

@@ -56,6 +56,7 @@ struct CnnRModelParams {
   const void* dfrag;       // dense A operand x 2^10: [ks 13][mt 4][term 2][64 lanes][8 f16]
   const float* dbias;      // [64] x 2^16
   float* out;              // S x 2^6 as f16 split planes: window-major [wtile][t][16 chunks][32][8 f16] or event-major
+  const float* c1tab;      // conv1 on the matrix pipe (NRV_CNNR_C1MFMA): [64 lanes][16]: A operand, -, -, -, bias 4, s1 x 2^6 4, h1 x 2^6 4
 };
 struct CnnRArgs {
   CnnRModelParams m[2];
@@ -82,6 +83,12 @@ struct CnnRArgs {
 #endif
 #ifndef NRV_CNNR_WAVES
 #define NRV_CNNR_WAVES 8
+#endif
+#ifndef NRV_CNNR_C1SGB
+#define NRV_CNNR_C1SGB 2                               // vector instructions behind each MFMA of a k-step's conv1 / dense interleave
+#endif
+#ifndef NRV_CNNR_C1MFMA
+#define NRV_CNNR_C1MFMA 0                              // 1: conv1 as v_mfma_f32_16x16x4_f32 (im2col on the B operand, r05: bit-identical, 1.5 us SLOWER); 0: on the VALU
 #endif
 constexpr int kCnnRWaves = NRV_CNNR_WAVES;             // conv / dense waves
 constexpr int kCnnRL1Waves = 4;                         // 6 -> 16 Bi-LSTM waves
@@ -224,8 +231,13 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
   // This guard covers FINITE overflow only: v_med3_f32 returns min3 when an operand is NaN, so a NaN sample drops out
   // of xmax (and +Inf is clamped to 3e38, still above every bound).  NaN samples are caught by the check on S, which a
   // NaN always reaches through conv2 and the dense layer (tests/test_gpu_range.py::test_nan_and_inf_samples pins both).
+#if !NRV_CNNR_C1MFMA
   float xmax = 0.f;
+#endif
   auto conv1_store = [&](lds_h* d, float xm, float xc, float xp) __attribute__((always_inline)) {
+#if NRV_CNNR_C1MFMA
+    (void)d; (void)xm; (void)xc; (void)xp;
+#else
     xmax = __builtin_amdgcn_fmed3f(__builtin_fabsf(xc), xmax, 3.0e38f);
     float c[8];
 #pragma unroll
@@ -247,7 +259,42 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     }
     *(lds_h8*)d = hi;
     *(lds_h8*)(d + 16 * 8) = lo;
+#endif
   };
+
+#if NRV_CNNR_C1MFMA
+  // conv1 on the matrix pipe (north_star: "conv1d ... lowered to im2col + MFMA GEMM"; nanorevcnn.py:24, 30): ONE
+  // v_mfma_f32_16x16x4_f32 gives the 8 channels of TWO positions of 16 events.  The B operand IS the im2col column:
+  // lane (event n, k = q) holds sample x[P - 1 + q], four consecutive samples of the event.  A [16][4]: rows 0-7 = channel
+  // co of position P (taps k = 0..2, k = 3 zero), rows 8-15 = channel co of position P + 1 (taps k = 1..3, k = 0 zero);
+  // C = the bias.  f32 in, f32 accumulate, k in order: bit for bit the fmaf chain b + x[p-1] w0 + x[p] w1 + x[p+1] w2 of
+  // the VALU form (the zero weight adds +-0).  Lane (n, q) receives channels 4 (q & 1) .. + 3 of position P + (q >> 1):
+  // ReLU, BatchNorm, split, and 8 bytes per term into the ring slot of that position.
+  const f32x4 k1a = *(const f32x4*)(P.c1tab + lane * 16);           // [0]: the A operand
+  const f32x4 k1b = *(const f32x4*)(P.c1tab + lane * 16 + 4);
+  const f32x4 k1s = *(const f32x4*)(P.c1tab + lane * 16 + 8);
+  const f32x4 k1h = *(const f32x4*)(P.c1tab + lane * 16 + 12);
+  typedef __attribute__((address_space(3))) f16x4r lds_h4;
+  lds_h* const rqh = c1 + (q >> 1) * kCnnRSlot + n * 8 + 4 * (q & 1);          // position P + (q >> 1), P even: never wraps
+  lds_h* const wslot = (lds_h*)c1_s + kCnnRWaves * kCnnRC1Wave + kCnnRSlot + n * 8 + 4 * (q & 1);   // the write-only slot
+  float xmax = 0.f;
+  // positions P, P + 1 (P even, compile-time) from xb = x[P - 1 + q] of this lane's event
+  auto conv1_mfma = [&](int Pp, float xb) __attribute__((always_inline)) {
+    xmax = __builtin_amdgcn_fmed3f(__builtin_fabsf(xb), xmax, 3.0e38f);
+    const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1a[0], xb, k1b, 0, 0, 0);
+    float c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(relu_acc(acc[r]), k1s[r], k1h[r]);
+    const f16x2r h01 = __builtin_convertvector(f32x2r{c[0], c[1]}, f16x2r);
+    const f16x2r h23 = __builtin_convertvector(f32x2r{c[2], c[3]}, f16x2r);
+    const f16x2r l01 = __builtin_convertvector(f32x2r{NRV_LO(c[0], h01[0]), NRV_LO(c[1], h01[1])}, f16x2r);
+    const f16x2r l23 = __builtin_convertvector(f32x2r{NRV_LO(c[2], h23[0]), NRV_LO(c[3], h23[1])}, f16x2r);
+    lds_h* d = rqh + (Pp % kCnnRRing) * kCnnRSlot;
+    if (Pp + 1 >= kSig) d = (Pp + (q >> 1) < kSig) ? d : wslot;      // a position past the window: not into the ring
+    *(lds_h4*)d = f16x4r{h01[0], h01[1], h23[0], h23[1]};
+    *(lds_h4*)(d + 16 * 8) = f16x4r{l01[0], l01[1], l23[0], l23[1]};
+  };
+#endif
 
   // units of 16 events: unit u = 2 * tile + sub
   // Units are dealt WORKGROUP-first (unit u -> workgroup u % G, then that workgroup's waves in turn): the bench step's
@@ -280,6 +327,17 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     // (Fetching the NEXT unit's first samples in this unit's last two k-steps, which load nothing useful, was built
     // and measured: 73 us instead of 65.)
     float xa[3], xres[2];
+#if NRV_CNNR_C1MFMA
+    {
+      // x[P - 1 + q] for P = 0, 2 (set 0) now, for P = 4, 6 (set 1) in flight
+      const float xb0 = buf_load4(rs, rok && q > 0 ? xq - 4u : kOut, 0), xb1 = ldq(1);
+      xa[0] = ldq(3); xa[1] = ldq(5); xa[2] = 0.f;
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(2 * pi);
+      conv1_mfma(0, xb0);
+      conv1_mfma(2, xb1);
+    }
+#else
     {
       const float x0 = buf_load4(rs, rok && q > 0 ? xq - 4u : kOut, 0), x1 = ldq(0), x2 = ldq(1);
 #pragma unroll
@@ -288,6 +346,7 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
       for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(2 * pi);
       conv1_store(slot_c(0), x0, x1, x2);
     }
+#endif
 
     f32x4 S[4];
 #pragma unroll
@@ -334,6 +393,20 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
       }
       // conv1 of the NEXT set (positions 4 ks + 4 .. + 7; pair B below needs its first position), samples one step ahead
       const float xr0 = xres[0] * kCnnRImgScale, xr1 = xres[1] * kCnnRImgScale;
+#if NRV_CNNR_C1MFMA
+      {
+        const float xb0 = xa[0], xb1 = xa[1];
+        xa[0] = ldq(4 * (ks + 2) - 1);
+        xa[1] = ldq(4 * (ks + 2) + 1);
+        if (ks + 1 < NKS) {
+#pragma unroll
+          for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(4 * (ks + 1) + 2 * pi);
+        }
+        const int C = 4 * (ks + 1);                    // positions C .. C + 3
+        if (C < kSig) conv1_mfma(C, xb0);
+        if (C + 2 < kSig) conv1_mfma(C + 2, xb1);
+      }
+#else
       {
         const float x0 = xa[0], x1 = xa[1], x2 = xa[2];
 #pragma unroll
@@ -353,7 +426,14 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
 #endif
         }
       }
-#if NRV_CNNR_SGB
+#endif
+#if NRV_CNNR_SGB && NRV_CNNR_C1MFMA
+#pragma unroll
+      for (int i = 0; i < 14; ++i) {                         // 12 dense products + the two conv1 products, ~30 vector instructions
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NRV_CNNR_C1SGB, 0);
+      }
+#elif NRV_CNNR_SGB
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA

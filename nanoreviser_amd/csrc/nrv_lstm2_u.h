@@ -24,6 +24,9 @@ namespace nrv {
 // grid = (ceil(rows / 64), 2 directions, 2 models), block = 512: four chains of two waves.
 // ---------------------------------------------------------------------------------------
 constexpr int kL2uThreads = 512;
+#ifndef NRV_L2U_EXP
+#define NRV_L2U_EXP 0      // timing experiments (results WRONG): 1 no barrier in the exchange, 2 no gate arithmetic, 4 no matrix products
+#endif
 
 template <int ACT>
 __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const int T, const int dir, const int rb,
@@ -74,6 +77,10 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
   GateSt gs;
   auto gate_stage = [&](int u, int r, int st, int t_out) __attribute__((always_inline)) {
     const int e = 4 * u + r;
+#if NRV_L2U_EXP & 2
+    if (st == 0) { hN[0][e] = (_Float16)Z[u][r]; hN[1][e] = (_Float16)Z[6 + u][r]; }
+    return;
+#endif
     if (st == 0) { gs.zi = Z[0 + u][r]; gs.zf = Z[2 + u][r]; gs.cp = c[e]; }
     else if (st == 1) { gs.zg = Z[4 + u][r]; gs.zo = Z[6 + u][r]; }
     else if (st == 2) {
@@ -143,7 +150,11 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {
         const f16x8 a = __builtin_bit_cast(f16x8, PA[pr] ? wr[ci % NR].lo : wr[ci % NR].hi);
+#if NRV_L2U_EXP & 4
+        Z[g * 2 + u][pr] += (float)a[0] + (float)hB[kb][PB[pr]][1];
+#else
         Z[g * 2 + u] = mfma16_f16(a, hB[kb][PB[pr]], Z[g * 2 + u]);
+#endif
         if (u > 0) {
           const int tk = (ci & 7) * 3 + pr;             // tick inside this unit tile: 0..23
 #pragma unroll
@@ -172,7 +183,11 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {
         const f16x8 a = __builtin_bit_cast(f16x8, PA[pr] ? wr[ci % NR].lo : wr[ci % NR].hi);
+#if NRV_L2U_EXP & 4
+        Z[g * 2 + u][pr] += (float)a[0] + (float)xb[PB[pr]][1];
+#else
         Z[g * 2 + u] = mfma16_f16(a, xb[PB[pr]], Z[g * 2 + u]);
+#endif
         if constexpr (GATES1) {
           const int tk = k * 3 + pr;                    // 0..23; the gates of unit tile 1 take ticks 0..11
           if (tk < 12) {
@@ -189,7 +204,9 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
     f32x4* const img = hx + p * 4 * 64 + lane;          // [kb 2][term 2][64 lanes]
     img[(hf * 2 + 0) * 64] = __builtin_bit_cast(f32x4, hN[0]);
     img[(hf * 2 + 1) * 64] = __builtin_bit_cast(f32x4, hN[1]);
+#if !(NRV_L2U_EXP & 1)
     __syncthreads();
+#endif
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

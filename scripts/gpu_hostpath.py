@@ -1,5 +1,5 @@
 """Where a host-pointer call's wall time goes (NRV_HOST_TRACE=1: registration, pipeline, unregistration) for nrv_predict
-at several call sizes, with and without registration of the caller's arrays.  python3 scripts/gpu_hostpath.py"""
+at several call sizes.  python3 scripts/gpu_hostpath.py [lib.so]"""
 import os, sys, time
 import numpy as np
 os.environ["NRV_HOST_TRACE"] = "1"
@@ -9,7 +9,7 @@ from nanoreviser_amd.weights import load_species
 from nanoreviser_amd import workload as O
 m1, m2 = load_species("ecoli")
 T = 13
-rv = Reviser(m1.with_window(T), m2.with_window(T))
+rv = Reviser(m1.with_window(T), m2.with_window(T), lib_path=(os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else None))
 sig0, rd0 = O.synth_windows(4096, T)
 rv.predict_pair(sig0, rd0)
 for G in (8, 32):

@@ -21,7 +21,7 @@ def short(name):
             ", ".join(m.groups()), name)
     if "lstm1_kernel" in name:
         return "lstm1"
-    if "lstm2_t_kernel" in name:
+    if "lstm2_t_kernel" in name or "lstm2_u_kernel" in name:
         return "lstm2"
     if "cnn_r_kernel" in name:
         return "cnn_r_kernel"
