@@ -502,15 +502,24 @@ struct nrv_handle {
   hipEvent_t ev_fork = nullptr;
   // staging for the host-pointer entry points
   // two staging sets [set][..]: the upload of group g+1 (copy stream) overlaps the kernels of group g
-  float *d_sig[2] = {0, 0}, *d_feat[2] = {0, 0}, *d_p[2][2] = {{0, 0}, {0, 0}};
+  // inputs: THREE staging sets (stage g uses set g % 3): the upload of stage g+1 is enqueued before the kernels of stage g, so it
+  // has two stages' time to arrive (with two sets it could only be enqueued after stage g-1's results had been handed over, and
+  // ended a few % after the running stage did: r05, 0.359 ms per stage against 0.327 device-resident); outputs: two sets
+  static constexpr int kIn = 3;
+  float *d_sig[kIn] = {0, 0, 0}, *d_feat[kIn] = {0, 0, 0}, *d_p[2][2] = {{0, 0}, {0, 0}};
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
+  // ONE device block per staging set, laid out as its page-locked mirror pin_out: [p1 rows x 6 f32 | p2 rows x 5 f32 | a1 rows |
+  // a2 rows | range-guard counter]: a stage's results come back in ONE copy (r05: six copies of ~13 us each stood between a
+  // stage's last kernel and the host's hand-over, and the next upload, enqueued behind that, ended after the running stage did)
+  char* d_out[2] = {0, 0};
+  unsigned* d_sat_st[2] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;      // host -> device
   hipStream_t d2h_stream = nullptr;       // device -> host (its own stream: an upload never queues behind a download)
-  hipEvent_t ev_in[2] = {0, 0}, ev_done[2] = {0, 0}, ev_out[2] = {0, 0};
+  hipEvent_t ev_in[kIn] = {0, 0, 0}, ev_done[2] = {0, 0}, ev_out[2] = {0, 0};
   // page-locked host staging: outputs always land here first (46 B per window); inputs only when the
   // caller's arrays could not be registered in place (bounce copies)
   char* pin_out[2] = {0, 0};
-  char *pin_sig[2] = {0, 0}, *pin_feat[2] = {0, 0};
+  char *pin_sig[kIn] = {0, 0, 0}, *pin_feat[kIn] = {0, 0, 0};
   size_t pin_sig_cap = 0, pin_feat_cap = 0;
   int host_register = 1;                  // NRV_HOST_REGISTER=0: never hipHostRegister caller memory
   // raw-read entry points: samples, event starts and read descriptors of the current call
@@ -791,17 +800,20 @@ static void free_workspace(nrv_handle* h) {
   for (int m = 0; m < 2; ++m) {
     (void)hipFree(h->S[m]); (void)hipFree(h->X1[m]); (void)hipFree(h->X2[m]); (void)hipFree(h->X3[m]);
     (void)hipFree(h->MO[m]); h->MO[m] = nullptr;
-    for (int st = 0; st < 2; ++st) {
-      (void)hipFree(h->d_p[st][m]); (void)hipFree(h->d_a[st][m]);
-      h->d_p[st][m] = nullptr; h->d_a[st][m] = nullptr;
-    }
+    for (int st = 0; st < 2; ++st) { h->d_p[st][m] = nullptr; h->d_a[st][m] = nullptr; }
     h->S[m] = h->X1[m] = h->X2[m] = h->X3[m] = nullptr;
   }
   for (int st = 0; st < 2; ++st) {
+    (void)hipFree(h->d_out[st]);
+    h->d_out[st] = nullptr; h->d_sat_st[st] = nullptr; h->pin_sat[st] = nullptr; h->sat_seen[st] = 0;
+    (void)hipHostFree(h->pin_out[st]);
+    h->pin_out[st] = nullptr;
+  }
+  for (int st = 0; st < nrv_handle::kIn; ++st) {
     (void)hipFree(h->d_sig[st]); (void)hipFree(h->d_feat[st]);
     h->d_sig[st] = h->d_feat[st] = nullptr;
-    (void)hipHostFree(h->pin_out[st]); (void)hipHostFree(h->pin_sig[st]); (void)hipHostFree(h->pin_feat[st]);
-    h->pin_out[st] = h->pin_sig[st] = h->pin_feat[st] = nullptr;
+    (void)hipHostFree(h->pin_sig[st]); (void)hipHostFree(h->pin_feat[st]);
+    h->pin_sig[st] = h->pin_feat[st] = nullptr;
   }
   h->pin_sig_cap = h->pin_feat_cap = 0;
   h->cap_rows = 0;
@@ -862,15 +874,24 @@ static int ensure_workspace(nrv_handle* h) {
     HIPCHK(h, hipMemset(h->X1[m], 0, n1 * 4));
     HIPCHK(h, hipMemset(h->X2[m], 0, n2 * 4));
     HIPCHK(h, hipMemset(h->X3[m], 0, n3 * 4));
-    for (int st = 0; st < 2; ++st) {
-      HIPCHK(h, hipMalloc(&h->d_p[st][m], (size_t)rows * 8 * 4));
-      HIPCHK(h, hipMalloc(&h->d_a[st][m], (size_t)rows));
-    }
   }
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < nrv_handle::kIn; ++st) {
     HIPCHK(h, hipMalloc(&h->d_sig[st], (size_t)rows * T * kSig * 4 + 4096));
     HIPCHK(h, hipMalloc(&h->d_feat[st], (size_t)rows * T * kFeat * 4 + 4096));
-    HIPCHK(h, hipHostMalloc((void**)&h->pin_out[st], (size_t)rows * kOutBytes, hipHostMallocDefault));
+  }
+  for (int st = 0; st < 2; ++st) {
+    const size_t ob = (size_t)rows * kOutBytes;              // rows is a multiple of kRowPad: the counter behind it is aligned
+    HIPCHK(h, hipMalloc((void**)&h->d_out[st], ob + 64));
+    HIPCHK(h, hipMemset(h->d_out[st], 0, ob + 64));
+    HIPCHK(h, hipHostMalloc((void**)&h->pin_out[st], ob + 64, hipHostMallocDefault));
+    memset(h->pin_out[st], 0, ob + 64);
+    h->d_p[st][0] = (float*)h->d_out[st];
+    h->d_p[st][1] = (float*)(h->d_out[st] + (size_t)rows * 24);
+    h->d_a[st][0] = (int8_t*)(h->d_out[st] + (size_t)rows * 44);
+    h->d_a[st][1] = (int8_t*)(h->d_out[st] + (size_t)rows * 45);
+    h->d_sat_st[st] = (unsigned*)(h->d_out[st] + ob);
+    h->pin_sat[st] = (unsigned*)(h->pin_out[st] + ob);
+    h->sat_seen[st] = 0;
   }
   h->cap_rows = rows;
   return NRV_OK;
@@ -1315,19 +1336,15 @@ int nrv_create(const nrv_weights* m1, const nrv_weights* m2, int T, int device, 
   h->stream = h->own_stream;
   bool ok = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int st = 0; st < nrv_handle::kIn && ok; ++st) ok = hipEventCreateWithFlags(&h->ev_in[st], hipEventDisableTiming) == hipSuccess;
   for (int st = 0; st < 2 && ok; ++st)
-    ok = hipEventCreateWithFlags(&h->ev_in[st], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_done[st], hipEventDisableTiming) == hipSuccess &&
+    ok = hipEventCreateWithFlags(&h->ev_done[st], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_out[st], hipEventDisableTiming) == hipSuccess;
   if (const char* e2 = getenv("NRV_HOST_REGISTER")) h->host_register = atoi(e2) != 0;
   if (const char* e3 = getenv("NRV_LANES")) h->lanes_on = atoi(e3) != 0;
   if (const char* e4 = getenv("NRV_COALESCE")) h->coalesce = atoi(e4) != 0;
   ok = ok && hipMalloc((void**)&h->d_sat, 4 * sizeof(unsigned)) == hipSuccess &&
        hipMemset(h->d_sat, 0, 4 * sizeof(unsigned)) == hipSuccess;
-  for (int st = 0; st < 2 && ok; ++st) {
-    ok = hipHostMalloc((void**)&h->pin_sat[st], sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
-    if (ok) *h->pin_sat[st] = 0;
-  }
   if (!ok) { g_create_error = "nrv_create: could not create the copy stream / events / counters"; nrv_destroy(h); return NRV_E_HIP; }
   if ((rc = upload_model(h, 0, b1, 6)) || (rc = upload_model(h, 1, b2, 5)) || (rc = ensure_workspace(h))) {
     g_create_error = h->err;
@@ -1353,14 +1370,13 @@ void nrv_destroy(nrv_handle* h) {
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
   if (h->d2h_stream) { (void)hipStreamSynchronize(h->d2h_stream); (void)hipStreamDestroy(h->d2h_stream); }
+  for (int st = 0; st < nrv_handle::kIn; ++st) if (h->ev_in[st]) (void)hipEventDestroy(h->ev_in[st]);
   for (int st = 0; st < 2; ++st) {
-    if (h->ev_in[st]) (void)hipEventDestroy(h->ev_in[st]);
     if (h->ev_done[st]) (void)hipEventDestroy(h->ev_done[st]);
     if (h->ev_out[st]) (void)hipEventDestroy(h->ev_out[st]);
   }
   (void)hipFree(h->d_raw); (void)hipFree(h->d_starts); (void)hipFree(h->d_reads);
   (void)hipFree(h->d_sat);
-  for (int st = 0; st < 2; ++st) (void)hipHostFree(h->pin_sat[st]);
   if (h->ev_raw) (void)hipEventDestroy(h->ev_raw);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -1563,14 +1579,14 @@ struct HostPin {
   }
 };
 
-static int grow_pinned(nrv_handle* h, char* (&buf)[2], size_t* cap, size_t need) {
+static int grow_pinned(nrv_handle* h, char* (&buf)[nrv_handle::kIn], size_t* cap, size_t need) {
   if (need <= *cap) return NRV_OK;
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < nrv_handle::kIn; ++st) {
     (void)hipHostFree(buf[st]);
     buf[st] = nullptr;
   }
   *cap = 0;
-  for (int st = 0; st < 2; ++st) HIPCHK(h, hipHostMalloc((void**)&buf[st], need, hipHostMallocDefault));
+  for (int st = 0; st < nrv_handle::kIn; ++st) HIPCHK(h, hipHostMalloc((void**)&buf[st], need, hipHostMallocDefault));
   *cap = need;
   return NRV_OK;
 }
@@ -1584,10 +1600,10 @@ static int grow_pinned(nrv_handle* h, char* (&buf)[2], size_t* cap, size_t need)
 //            straight from there; arrays too small to be worth it, or not registrable, are bounced
 //            through pinned staging by a host memcpy that overlaps the previous group's kernels;
 //   outputs  land in pinned staging (46 B per window) and are handed to the caller one group behind.
-//   h2d:      [wait done(g-2)] upload(g) -> in(g)
-//   compute:  wait in(g), out(g-2); kernels(g) -> done(g)
-//   d2h:      wait done(g); download(g) -> out(g)
-//   host:     wait out(g-1); copy it to the caller; stage group g+1
+//   h2d:      upload(g+1) -> in(g+1)          (three input sets: enqueued before the kernels of stage g)
+//   compute:  wait in(g); kernels(g) -> done(g)
+//   d2h:      wait done(g); download(g) -> out(g)   (one block: p1 | p2 | a1 | a2 | range-guard counter)
+//   host:     wait out(g-1); copy it to the caller; next iteration
 static int predict_host(nrv_handle* h, const float* sig, const float* feat, int64_t n_in, bool read_mode,
                         float* p1, float* p2, int8_t* a1, int8_t* a2, int raw_reads = 0) {
   int rc = check_handle(h);
@@ -1611,31 +1627,28 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   if (!raw_reads && !direct_s && (rc = grow_pinned(h, h->pin_sig, &h->pin_sig_cap, ev_grp * kSig * 4))) return rc;
   if (!direct_f && (rc = grow_pinned(h, h->pin_feat, &h->pin_feat_cap, ev_grp * kFeat * 4))) return rc;
 
-  // One stage's launch groups (on the lanes when they are small) from staging set st.
-  auto run_stage = [&](int nb, int st) -> int {
+  // One stage's launch groups (on the lanes when they are small): inputs from staging set si, outputs to set st.
+  auto run_stage = [&](int nb, int si, int st) -> int {
     return for_groups(h, nb, [&](int64_t w, int nw) {
-      return run_group(h, h->d_sig[st] + (read_mode ? w * kSig : w * T * kSig),
-                       h->d_feat[st] + (read_mode ? w * kFeat : w * T * kFeat), nw, read_mode,
-                       h->d_p[st][0] + w * 6, h->d_p[st][1] + w * 5, h->d_a[st][0] + w, h->d_a[st][1] + w, h->d_sat + st);
+      return run_group(h, h->d_sig[si] + (read_mode ? w * kSig : w * T * kSig),
+                       h->d_feat[si] + (read_mode ? w * kFeat : w * T * kFeat), nw, read_mode,
+                       h->d_p[st][0] + w * 6, h->d_p[st][1] + w * 5, h->d_a[st][0] + w, h->d_a[st][1] + w, h->d_sat_st[st]);
     });
   };
-  auto finalize = [&](int64_t s, int nb, int st) -> int {          // group -> caller, one group behind
+  auto finalize = [&](int64_t s, int nb, int si, int st) -> int {  // stage -> caller, one stage behind
     HIPCHK(h, hipEventSynchronize(h->ev_out[st]));
     char* o = h->pin_out[st];
     const size_t rows = (size_t)h->cap_rows;
     if (*h->pin_sat[st] != h->sat_seen[st]) {
       // f16x2 range guard: the signal branch of this stage left the f16 range (a spike sample, a tiny MAD, a
-      // NaN).  Its inputs are still in staging set st (the set is reused two stages later): run the stage
+      // NaN).  Its inputs are still in staging set si (a set is reused three stages later): run the stage
       // again on the f32 kernels, which have no range limit, and take those results.
       const int h2 = h->h2, split = h->split;
       h->h2 = 0; h->split = 0;
-      int rc2 = run_stage(nb, st);
+      int rc2 = run_stage(nb, si, st);
       h->h2 = h2; h->split = split;
       if (rc2) return rc2;
-      if (p1) HIPCHK(h, hipMemcpyAsync(o, h->d_p[st][0], (size_t)nb * 24, hipMemcpyDeviceToHost, h->stream));
-      if (p2) HIPCHK(h, hipMemcpyAsync(o + rows * 24, h->d_p[st][1], (size_t)nb * 20, hipMemcpyDeviceToHost, h->stream));
-      if (a1) HIPCHK(h, hipMemcpyAsync(o + rows * 44, h->d_a[st][0], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
-      if (a2) HIPCHK(h, hipMemcpyAsync(o + rows * 45, h->d_a[st][1], (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(o, h->d_out[st], rows * kOutBytes + sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       h->sat_seen[st] = *h->pin_sat[st];
       h->sat_reruns += 1;
@@ -1646,55 +1659,69 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     if (a2) memcpy(a2 + s, o + rows * 45, (size_t)nb);
     return NRV_OK;
   };
-  int64_t g = 0, prev_s = 0;
-  int prev_nb = 0;
-  for (int64_t s = 0; s < n; s += stage, ++g) {
-    const int st = (int)(g & 1);
+  // Upload of the stage that starts at window s into input set si (raw-read mode: the features only; the samples went up
+  // with upload_raw and the windows are cut on the device).  ONE copy per array: two halves on two copy streams were measured
+  // (r05c: 3.40 vs 3.30 ms per 8-stage call) - a single stream already moves 53-57 GB/s whichever way the memory was
+  // page-locked (tools/microbench/h2d_rate.hip).
+  auto upload = [&](int64_t s, int si) -> int {
     const int nb = (int)((n - s < stage) ? (n - s) : stage);
     const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
-    const float* hs = raw_reads ? nullptr : sig + (read_mode ? s * kSig : s * T * kSig);
-    const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
-    // Staging set st was last used by stage g-2.  Nothing has to be waited for here: the previous iteration ended with
-    // finalize(g-2) - a HOST wait for that stage's download (ev_out), which ran behind its kernels (ev_done), which ran behind
-    // its upload (ev_in) - so its bounce buffers, d_sig / d_feat and d_p / d_a are all free again.  (Until r05 three waits stood
-    // here, one of them a barrier packet on the compute stream per stage.)
     if (!raw_reads) {
-      // ONE copy per stage: two halves on two copy streams were measured (r05c: 3.40 vs 3.30 ms per 8-stage call) - a single
-      // stream already moves 53-57 GB/s (tools/microbench/h2d_rate.hip), whichever way the memory was page-locked
+      const float* hs = sig + (read_mode ? s * kSig : s * T * kSig);
       const void* src = hs;
-      if (!direct_s) { memcpy(h->pin_sig[st], hs, ev * kSig * 4); src = h->pin_sig[st]; }
-      HIPCHK(h, hipMemcpyAsync(h->d_sig[st], src, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
+      if (!direct_s) { memcpy(h->pin_sig[si], hs, ev * kSig * 4); src = h->pin_sig[si]; }
+      HIPCHK(h, hipMemcpyAsync(h->d_sig[si], src, ev * kSig * 4, hipMemcpyHostToDevice, h->copy_stream));
     }
-    {
-      const void* src = hf;
-      if (!direct_f) { memcpy(h->pin_feat[st], hf, ev * kFeat * 4); src = h->pin_feat[st]; }
-      HIPCHK(h, hipMemcpyAsync(h->d_feat[st], src, ev * kFeat * 4, hipMemcpyHostToDevice, h->copy_stream));
-    }
-    HIPCHK(h, hipEventRecord(h->ev_in[st], h->copy_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[st], 0));
-    if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[st]);
-    if ((rc = run_stage(nb, st))) return rc;
+    const float* hf = feat + (read_mode ? s * kFeat : s * T * kFeat);
+    const void* src = hf;
+    if (!direct_f) { memcpy(h->pin_feat[si], hf, ev * kFeat * 4); src = h->pin_feat[si]; }
+    HIPCHK(h, hipMemcpyAsync(h->d_feat[si], src, ev * kFeat * 4, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_in[si], h->copy_stream));
+    return NRV_OK;
+  };
+  int64_t g = 0, prev_s = 0;
+  int prev_nb = 0;
+  // NRV_HOST_TRACE=2: timing events around every stage's kernels (span of the kernels, gap to the previous stage's)
+  static const bool trace2 = getenv("NRV_HOST_TRACE") && atoi(getenv("NRV_HOST_TRACE")) > 1;
+  std::vector<hipEvent_t> tev;
+  if ((rc = upload(0, 0))) return rc;
+  for (int64_t s = 0; s < n; s += stage, ++g) {
+    const int si = (int)(g % nrv_handle::kIn), st = (int)(g & 1);
+    const int nb = (int)((n - s < stage) ? (n - s) : stage);
+    const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
+    // Stage g+1's upload goes out FIRST, into the input set stage g-2 used.  Nothing has to be waited for: the previous
+    // iteration ended with finalize(g-2) - a HOST wait for that stage's download (ev_out), which ran behind its kernels
+    // (ev_done), which ran behind its upload (ev_in) - so that set's bounce buffers and d_sig / d_feat are free, and so are
+    // the output set d_p / d_a of stage g-2 that this stage's kernels write.  (Until r05 three waits stood here, one of them
+    // a barrier packet on the compute stream per stage.)
+    if (s + stage < n && (rc = upload(s + stage, (int)((g + 1) % nrv_handle::kIn)))) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[si], 0));
+    if (trace2 && tev.size() < 128) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); HIPCHK(h, hipEventRecord(e, h->stream)); tev.push_back(e); }
+    if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[si]);
+    if ((rc = run_stage(nb, si, st))) return rc;
+    if (trace2 && tev.size() < 128) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); HIPCHK(h, hipEventRecord(e, h->stream)); tev.push_back(e); }
     HIPCHK(h, hipEventRecord(h->ev_done[st], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, h->ev_done[st], 0));
-    {
-      char* o = h->pin_out[st];
-      const size_t rows = (size_t)h->cap_rows;
-      if (p1) HIPCHK(h, hipMemcpyAsync(o, h->d_p[st][0], (size_t)nb * 24, hipMemcpyDeviceToHost, h->d2h_stream));
-      if (p2) HIPCHK(h, hipMemcpyAsync(o + rows * 24, h->d_p[st][1], (size_t)nb * 20, hipMemcpyDeviceToHost, h->d2h_stream));
-      if (a1) HIPCHK(h, hipMemcpyAsync(o + rows * 44, h->d_a[st][0], (size_t)nb, hipMemcpyDeviceToHost, h->d2h_stream));
-      if (a2) HIPCHK(h, hipMemcpyAsync(o + rows * 45, h->d_a[st][1], (size_t)nb, hipMemcpyDeviceToHost, h->d2h_stream));
-      if (h->h2) HIPCHK(h, hipMemcpyAsync(h->pin_sat[st], h->d_sat + st, sizeof(unsigned), hipMemcpyDeviceToHost, h->d2h_stream));
-    }
+    HIPCHK(h, hipMemcpyAsync(h->pin_out[st], h->d_out[st], (size_t)h->cap_rows * kOutBytes + sizeof(unsigned), hipMemcpyDeviceToHost, h->d2h_stream));
     HIPCHK(h, hipEventRecord(h->ev_out[st], h->d2h_stream));
-    if (g >= 1 && (rc = finalize(prev_s, prev_nb, st ^ 1))) return rc;
+    if (g >= 1 && (rc = finalize(prev_s, prev_nb, (int)((g - 1) % nrv_handle::kIn), st ^ 1))) return rc;
     prev_s = s;
     prev_nb = nb;
   }
-  if ((rc = finalize(prev_s, prev_nb, (int)((g - 1) & 1)))) return rc;
+  if ((rc = finalize(prev_s, prev_nb, (int)((g - 1) % nrv_handle::kIn), (int)((g - 1) & 1)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->copy_stream));
   HIPCHK(h, hipStreamSynchronize(h->d2h_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   pin_s.settled = pin_f.settled = true;
+  if (trace2 && tev.size() >= 2) {
+    double span = 0, gap = 0; float ms = 0;
+    for (size_t i = 0; i + 1 < tev.size(); i += 2) { (void)hipEventElapsedTime(&ms, tev[i], tev[i + 1]); span += ms; }
+    for (size_t i = 1; i + 1 < tev.size(); i += 2) { (void)hipEventElapsedTime(&ms, tev[i], tev[i + 1]); gap += ms; }
+    (void)hipEventElapsedTime(&ms, tev.front(), tev.back());
+    fprintf(stderr, "[nrv host trace] %zu stages: kernels %.4f ms per stage, gap between stages %.4f ms, first kernel to last %.3f ms\n",
+            tev.size() / 2, span / (tev.size() / 2), tev.size() > 2 ? gap / (tev.size() / 2 - 1) : 0.0, ms);
+    for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+  }
   if (trace) {
     const double ms_run = since(t_0) - ms_reg;
     const auto t_u = std::chrono::steady_clock::now();

@@ -2,7 +2,7 @@
 at several call sizes.  python3 scripts/gpu_hostpath.py [lib.so]"""
 import os, sys, time
 import numpy as np
-os.environ["NRV_HOST_TRACE"] = "1"
+os.environ.setdefault("NRV_HOST_TRACE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nanoreviser_amd.engine import Reviser
 from nanoreviser_amd.weights import load_species
