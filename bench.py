@@ -363,14 +363,15 @@ def kernel_source_sha(precision):
 
 
 def step_source_sha():
-    """sha256 of every kernel source of the step (csrc/*.h + nrv_api.hip, comments and blank lines excluded): the
-    step-wide PMC figures (`traffic_step`) describe the library only while none of them has changed."""
+    """sha256 of every kernel source of the step (csrc/nrv_*.h: the kernels and the switches that choose between them; comments
+    and blank lines excluded): the step-wide PMC figures (`traffic_step`) describe the library only while none of them has
+    changed.  nrv_api.hip (host code: entry points, packing, pipeline) is left out on purpose."""
     import glob
     import hashlib
     import re
     hsh = hashlib.sha256()
     csrc = os.path.join(ROOT, "nanoreviser_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "nrv_*.h"))) + [os.path.join(csrc, "nrv_api.hip")]:
+    for f in sorted(glob.glob(os.path.join(csrc, "nrv_*.h"))):
         with open(f, "r") as fp:
             for line in fp:
                 code = re.sub(r"\s*//.*$", "", line.rstrip("\n")).rstrip()
