@@ -408,24 +408,50 @@ class NullEngine:
         pass
 
 
-def _hostcap_files(tmp, n_reads):
-    """n_reads hard links (copies where links are refused) of the committed fixture fast5 files -> (dir, names)."""
+def scratch_base():
+    """Where the file-based legs (host_capacity, cli_e2e) keep their inputs and OUTPUTS: a tmpfs (/dev/shm) when there is one with
+    room, else the default temporary directory.  Why: on the GPU boxes /tmp is the container's OVERLAY root, whose write path
+    costs ten times the system time of any real filesystem once a directory has seen a few thousand creates + renames (r05,
+    scripts/host_scaling.py: the same 8-worker host stage 68-78 M bases/s writing to the overlay, 120-131 M writing to tmpfs,
+    parser time identical) - a property of the sandbox, not of the host stage.  Returns (dir or None, description)."""
     import shutil
+    import tempfile
+    if os.environ.get("NRV_BENCH_SCRATCH"):
+        return os.environ["NRV_BENCH_SCRATCH"], "NRV_BENCH_SCRATCH"
+    try:
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > (4 << 30):
+            return "/dev/shm", "tmpfs (/dev/shm)"
+    except OSError:
+        pass
+    return None, "default temporary directory (%s)" % tempfile.gettempdir()
+
+
+def _hostcap_files(tmp, n_reads, copies=None):
+    """n_reads hard links of COPIES of the committed fixture fast5 files -> (dir, names).  `copies` distinct inodes per fixture
+    (default 32, NRV_HOSTCAP_COPIES): sixteen threads on two sockets reading the same two inodes contend for those inodes' page
+    cache in the kernel - a property of this synthetic file set, not of a real run (every read its own file)."""
+    import shutil
+    copies = int(os.environ.get("NRV_HOSTCAP_COPIES", "32")) if copies is None else copies
     gold = os.path.join(ROOT, "tests", "golden", "fast5")
     src = sorted(f for f in os.listdir(gold) if f.endswith(".fast5"))
     if not src:
         raise RuntimeError("no fixture fast5 files")
-    din = os.path.join(tmp, "in")
+    din, dcp = os.path.join(tmp, "in"), os.path.join(tmp, "copies")
     os.makedirs(din, exist_ok=True)
+    os.makedirs(dcp, exist_ok=True)
     names = []
     for i in range(n_reads):
         fn = f"r{i:06d}_{i % len(src)}.fast5"
         dst = os.path.join(din, fn)
         if not os.path.exists(dst):
+            j = (i // len(src)) % max(1, copies)
+            cp = os.path.join(dcp, f"c{j}_{src[i % len(src)]}") if copies > 0 else os.path.join(gold, src[i % len(src)])
+            if copies > 0 and not os.path.exists(cp):
+                shutil.copy(os.path.join(gold, src[i % len(src)]), cp)
             try:
-                os.link(os.path.join(gold, src[i % len(src)]), dst)
+                os.link(cp, dst)
             except OSError:
-                shutil.copy(os.path.join(gold, src[i % len(src)]), dst)
+                shutil.copy(cp, dst)
         names.append(fn)
     return din, names
 
@@ -469,9 +495,10 @@ def host_capacity(cores, min_s=2.0, max_reads=24000):
     import shutil
     import tempfile
     from nanoreviser_amd import cli
-    tmp = tempfile.mkdtemp(prefix="nrv_hostcap_")
+    base, base_what = scratch_base()
+    tmp = tempfile.mkdtemp(prefix="nrv_hostcap_", dir=base)
     per_read = 6800.0                                    # bases per fixture read, refined by the calibration pass
-    out = {"unit": "bases/s", "min_sample_s": min_s,
+    out = {"unit": "bases/s", "min_sample_s": min_s, "files_on": base_what,
            "what": "cli.process_files with an engine that computes nothing: fast5 parse, event collapse, statistics, packing, "
                    "merge, FASTA write of the committed fixture reads (hard links); fresh child process, one timed pass per point"}
     try:
@@ -505,35 +532,55 @@ def host_capacity(cores, min_s=2.0, max_reads=24000):
         for w in sorted({1, min(4, cores), cores}):
             one(f"workers_{w}", w, 64)
         one("cli_1gpu", cores, cli.kNativePoolMax)
-        # ---- eight GPU workers, as processes
+        # ---- eight GPU workers, as processes: three runs on the scratch filesystem (median + all), one writing to the default
+        # temporary directory (the sandbox's overlay root: see scratch_base)
         world = 8
         rate1 = out.get(f"workers_{cores}", 2e7)
-        n = int(min(max_reads, max(800, 1.25 * min_s * rate1 / per_read)))
+        n = int(min(max_reads, max(800, 1.25 * min_s * max(rate1, 8e7) / per_read)))
         din, names = _hostcap_files(tmp, n)
         ctx = mp.get_context("spawn")
-        barrier, q = ctx.Barrier(world + 1), ctx.Queue()
-        procs = [ctx.Process(target=_hostcap_worker, args=(r, world, din, names[r::world], os.path.join(tmp, f"out8_{r}"), cores, barrier, q))
-                 for r in range(world)]
-        for pr in procs:
-            pr.start()
-        try:
-            barrier.wait(180)
-            t0 = time.perf_counter()
-            res = [q.get(timeout=300) for _ in procs]
-            dt = time.perf_counter() - t0
-            errs = [e for _, _, _, e in res if e]
-            if errs:
-                out["cli_8gpu_workers"] = {"error": errs[0]}
-            else:
-                out["cli_8gpu_workers"] = sum(b for _, b, _, _ in res) / dt
-                out["cli_8gpu_workers_detail"] = {"reads": n, "seconds": dt, "worker_processes": world,
-                                                  "parser_threads_per_worker": sorted({t for _, _, t, _ in res})}
-        except Exception as e:
-            out["cli_8gpu_workers"] = {"error": repr(e)}
-        for pr in procs:
-            pr.join(30)
-            if pr.is_alive():
-                pr.terminate()
+
+        def eight(out_root):
+            barrier, q = ctx.Barrier(world + 1), ctx.Queue()
+            procs = [ctx.Process(target=_hostcap_worker, args=(r, world, din, names[r::world], os.path.join(out_root, f"out8_{r}"), cores, barrier, q))
+                     for r in range(world)]
+            for pr in procs:
+                pr.start()
+            try:
+                barrier.wait(180)
+                t0 = time.perf_counter()
+                res = [q.get(timeout=300) for _ in procs]
+                dt = time.perf_counter() - t0
+                errs = [e for _, _, _, e in res if e]
+                if errs:
+                    return {"error": errs[0]}
+                return {"rate": sum(b for _, b, _, _ in res) / dt, "seconds": dt, "threads": sorted({t for _, _, t, _ in res})}
+            except Exception as e:
+                return {"error": repr(e)}
+            finally:
+                for pr in procs:
+                    pr.join(30)
+                    if pr.is_alive():
+                        pr.terminate()
+                for r in range(world):
+                    shutil.rmtree(os.path.join(out_root, f"out8_{r}"), ignore_errors=True)
+        runs = [eight(tmp) for _ in range(3)]
+        good = sorted(r["rate"] for r in runs if "rate" in r)
+        if good:
+            out["cli_8gpu_workers"] = good[len(good) // 2]
+            out["cli_8gpu_workers_detail"] = {"reads": n, "runs": [r.get("rate", r.get("error")) for r in runs],
+                                              "seconds": [r.get("seconds") for r in runs], "worker_processes": world,
+                                              "parser_threads_per_worker": runs[0].get("threads")}
+        else:
+            out["cli_8gpu_workers"] = {"error": runs[0].get("error")}
+        if base is not None:
+            slow = tempfile.mkdtemp(prefix="nrv_hostcap_out_")
+            try:
+                r = eight(slow)
+                out["cli_8gpu_workers_writing_to_default_tmp"] = r.get("rate", r.get("error"))
+                out["default_tmp"] = tempfile.gettempdir()
+            finally:
+                shutil.rmtree(slow, ignore_errors=True)
         return out
     except Exception as e:
         out["error"] = repr(e)
@@ -939,7 +986,8 @@ def cli_e2e(reps, threads, gpus=1, share=False):
     import shutil
     import tempfile
     src = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fast5", "*.fast5")))
-    work = tempfile.mkdtemp(prefix="nrv_cli_e2e_")
+    base, base_what = scratch_base()
+    work = tempfile.mkdtemp(prefix="nrv_cli_e2e_", dir=base)
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NRV_BENCH_CHILD"):
         env.pop(k, None)                                     # the command line is not a rank of this job
@@ -951,7 +999,7 @@ def cli_e2e(reps, threads, gpus=1, share=False):
         for i, f in enumerate(src):
             for k in range(reps * gpus):
                 os.symlink(f, os.path.join(din, f"r{i}_{k}.fast5"))
-        res = {"reads": len(src) * reps * gpus, "threads": threads, "n_gpus": gpus, "share_device": bool(share)}
+        res = {"reads": len(src) * reps * gpus, "threads": threads, "n_gpus": gpus, "share_device": bool(share), "files_on": base_what}
         for name, n in (("start_up", 2), ("run", None)):     # two reads first: what a run costs before it streams
             if n is not None:
                 d2 = os.path.join(work, "in2")

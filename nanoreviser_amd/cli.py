@@ -845,11 +845,27 @@ def gpu_local_cpus(device: int, sysfs: str = "/sys") -> Optional[List[int]]:
         return None
 
 
+def primary_threads(cpus: Sequence[int], sysfs: str = "/sys") -> List[int]:
+    """One logical CPU per physical core: the lowest-numbered hardware thread of every core that has a thread in `cpus`.
+    Two busy hardware threads of one core each run at ~60 % speed and are charged full CPU time: under a cgroup CPU quota
+    the same host stage delivered 70-80 M or 115-125 M bases/s depending on where the scheduler happened to put the parser
+    threads (r05, 2 x 64 cores x 2 threads, quota 16: scripts/host_scaling.py).  Without topology information: `cpus`."""
+    keep, have = [], set(cpus)
+    try:
+        for c in sorted(have):
+            sib = _cpulist(open(os.path.join(sysfs, "devices", "system", "cpu", f"cpu{c}", "topology", "thread_siblings_list")).read())
+            if c == min(x for x in sib if x in have):
+                keep.append(c)
+    except Exception:
+        return sorted(have)
+    return keep or sorted(have)
+
+
 def worker_cpus(rank: int, world: int, devices: Optional[Sequence[int]] = None, allowed: Optional[Sequence[int]] = None,
                 sysfs: str = "/sys") -> Optional[List[int]]:
     """The cores GPU worker `rank` of `world` pins itself to (NanoReviser.py:203-219 leaves its Pool wherever the kernel
-    puts it), or None = leave the affinity alone.  The cores this process may use are divided so that each worker gets
-    cores of ITS GPU's NUMA node (fast5 buffers, pinned staging memory and the HIP runtime's threads then sit next to the
+    puts it), or None = leave the affinity alone.  The cores this process may use - one hardware thread of each
+    (`primary_threads`) - are divided so that each worker gets cores of ITS GPU's NUMA node (fast5 buffers, pinned staging memory and the HIP runtime's threads then sit next to the
     GPU's PCIe root); workers whose GPUs share a node share its cores evenly; without NUMA information the allowed
     cores are cut into `world` contiguous slices.  NRV_CPU_AFFINITY=0 turns it off; fewer than two cores per worker: off."""
     if os.environ.get("NRV_CPU_AFFINITY", "1") == "0" or world < 1:
@@ -860,6 +876,9 @@ def worker_cpus(rank: int, world: int, devices: Optional[Sequence[int]] = None, 
         return None
     if len(allowed) < 2 * world:
         return None
+    prim = primary_threads(allowed, sysfs)             # one hardware thread per core, when that still leaves two per worker
+    if len(prim) >= 2 * world:
+        allowed = prim
     devices = list(devices) if devices is not None else list(range(world))
     aset = set(allowed)
     local = []

@@ -24,21 +24,55 @@ def worker(rank, world, din, names, out_dir, threads, barrier, q):
     os.environ["NRV_PARSER_THREADS_MAX"] = "64"
     cli.process_files(args, names[:8], bench.NullEngine(), lambda m: None, core_share=threads)
     barrier.wait(120)
+    # per-thread CPU (user, system) by thread name: a sampler keeps the last /proc/self/task/<tid>/stat of every thread it saw
+    import threading
+    seen, names_of, stop = {}, {}, threading.Event()
+    tck = os.sysconf("SC_CLK_TCK")
+
+    def sample():
+        while not stop.is_set():
+            for th in threading.enumerate():
+                if th.native_id is not None:
+                    names_of[th.native_id] = th.name.split("_")[0].rstrip("0123456789-") or th.name
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    f = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+                    seen[int(tid)] = (int(f[11]) / tck, int(f[12]) / tck)
+                except Exception:
+                    pass
+            stop.wait(0.02)
+    base = {}
+    for tid in os.listdir("/proc/self/task"):
+        f = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+        base[int(tid)] = (int(f[11]) / tck, int(f[12]) / tck)
+    smp = threading.Thread(target=sample, name="sampler", daemon=True)
+    smp.start()
     r0 = resource.getrusage(resource.RUSAGE_SELF)
     st = cli.process_files(args, names, bench.NullEngine(), lambda m: None, core_share=threads)
     r1 = resource.getrusage(resource.RUSAGE_SELF)
-    q.put((rank, st["bases"], st["parser_workers"], (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime), st["host_s"]))
+    stop.set()
+    smp.join()
+    by = {}
+    for tid, (u, sy) in seen.items():
+        u0, s0 = base.get(tid, (0.0, 0.0))
+        nm = names_of.get(tid, "other")
+        a = by.setdefault(nm, [0.0, 0.0])
+        a[0] += u - u0
+        a[1] += sy - s0
+    q.put((rank, st["bases"], st["parser_workers"], (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime), st["host_s"],
+           r1.ru_stime - r0.ru_stime, by))
 
 
 if __name__ == "__main__":
     total = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
-    tmp = tempfile.mkdtemp(prefix="nrv_hostscale_")
+    tmp = tempfile.mkdtemp(prefix="nrv_hostscale_", dir=os.environ.get("HOST_SCALING_TMP"))
+    odir = tempfile.mkdtemp(prefix="nrv_hostscale_out_", dir=os.environ.get("HOST_SCALING_OUT", os.environ.get("HOST_SCALING_TMP")))
     din, names = bench._hostcap_files(tmp, total)
     ctx = mp.get_context("spawn")
     print("cores:", bench.host_cores())
-    for P, t in ((8, 2), (8, 3), (8, 4), (4, 4), (4, 8), (2, 8), (1, 16), (16, 1), (16, 2)):
+    for P, t in [tuple(int(x) for x in c.split("x")) for c in os.environ.get("HOST_SCALING", "8x2,8x3,8x4,4x4,4x8,2x8,1x16,16x1,16x2").split(",")]:
         barrier, q = ctx.Barrier(P + 1), ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, P, din, names[r::P], os.path.join(tmp, f"o{P}_{t}_{r}"), t, barrier, q)) for r in range(P)]
+        procs = [ctx.Process(target=worker, args=(r, P, din, names[r::P], os.path.join(odir, f"o{P}_{t}_{r}"), t, barrier, q)) for r in range(P)]
         for p in procs:
             p.start()
         barrier.wait(180)
@@ -48,8 +82,14 @@ if __name__ == "__main__":
         for p in procs:
             p.join(30)
         b = sum(r[1] for r in res); cpu = sum(r[3] for r in res); hs = sum(r[4] for r in res)
+        agg = {}
+        for r in res:
+            for k, (u, sy) in r[6].items():
+                a = agg.setdefault(k, [0.0, 0.0]); a[0] += u; a[1] += sy
         print(f"{P:2d} processes x {t:2d} parser threads ({sorted({r[2] for r in res})} used): {b / dt / 1e6:6.1f} M bases/s, wall {dt:.2f} s, "
-              f"CPU {cpu:.1f} s = {cpu / dt:.1f} cores busy, parser C time {hs:.1f} s ({hs / total * 1e3:.2f} ms per read)", flush=True)
+              f"CPU {cpu:.1f} s = {cpu / dt:.1f} cores busy (system {sum(r[5] for r in res):.1f} s), parser C time {hs:.1f} s ({hs / total * 1e3:.2f} ms per read); "
+              "by thread (user+sys s): " + ", ".join(f"{k} {u:.1f}+{sy:.1f}" for k, (u, sy) in sorted(agg.items(), key=lambda kv: -sum(kv[1]))), flush=True)
         for r in range(P):
-            shutil.rmtree(os.path.join(tmp, f"o{P}_{t}_{r}"), ignore_errors=True)
+            shutil.rmtree(os.path.join(odir, f"o{P}_{t}_{r}"), ignore_errors=True)
     shutil.rmtree(tmp, ignore_errors=True)
+    shutil.rmtree(odir, ignore_errors=True)

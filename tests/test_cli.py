@@ -280,6 +280,17 @@ def test_gpu_workers_are_pinned_to_their_gpus_numa_cores(tmp_path, monkeypatch):
     # no topology (this container): contiguous slices of what is allowed; too few cores or NRV_CPU_AFFINITY=0: hands off
     assert cli.worker_cpus(1, 2, allowed=range(8), sysfs=str(tmp_path / "none")) == [4, 5, 6, 7]
     assert cli.worker_cpus(0, 8, allowed=range(8), sysfs=sysfs) is None
+    # two hardware threads per core (cpu k and k + 64 are siblings): workers get ONE thread of each core, so that two busy parser
+    # threads never share a core (r05: the same host stage ran at 70-80 M or 115-125 M bases/s depending on that placement)
+    for c in range(128):
+        d = tmp_path / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(f"{c % 64},{c % 64 + 64}\n")
+    assert cli.primary_threads(range(128), sysfs) == list(range(64))
+    assert cli.primary_threads([3, 64, 67, 70], sysfs) == [3, 64, 70]           # a core whose first thread is not ours keeps the other
+    smt = [cli.worker_cpus(r, 8, allowed=range(128), sysfs=sysfs) for r in range(8)]
+    assert all(len(c) == 8 and max(c) < 64 for c in smt) and len(set().union(*map(set, smt))) == 64
+    assert all(set(c) <= set(cli.gpu_local_cpus(r, sysfs)) for r, c in enumerate(smt))
     monkeypatch.setenv("NRV_CPU_AFFINITY", "0")
     assert cli.worker_cpus(0, 2, allowed=range(128), sysfs=sysfs) is None
 
