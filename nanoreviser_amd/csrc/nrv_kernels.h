@@ -19,7 +19,7 @@
 //   * FIVE launches per group of 4096 windows in the default (f16x2) mode:
 //       cnn_r_kernel      signal branch (conv1 on the VALU -> conv2 -> dense 400->64 on the matrix pipe, in registers)
 //                         + the 6->16 Bi-LSTM (lstm1_unit) as four more waves of the same workgroups
-//       lstm2_t_kernel    32->64 Bi-LSTM, transposed products, wave-private recurrence
+//       lstm2_u_kernel    32->64 Bi-LSTM, transposed products, two waves per 16-row chain (r05; lstm2_t_kernel: one wave per chain)
 //       lstm_h2w_kernel   192->128 Bi-LSTM, 16x16x32 f16 tiles, eight waves: two per SIMD running a step in opposite order
 //       lstm_h2s_kernel   256->64 Bi-LSTM <64,0,64,...>, 16x16x32 f16 tiles, one wave per SIMD
 //       head_h2_kernel    per-timestep MLP 128->128->32->6 + flatten, feature dense, softmax, argmax

@@ -24,6 +24,9 @@ namespace nrv {
 // grid = (ceil(rows / 64), 2 directions, 2 models), block = 512: four chains of two waves.
 // ---------------------------------------------------------------------------------------
 constexpr int kL2uThreads = 512;
+#ifndef NRV_L2U_ILP
+#define NRV_L2U_ILP 0      // 1: gate pieces stage-major over the four elements of a unit tile (independent neighbours; r05: 35.3-36.0 vs 34.9-35.7 us, nothing); 0: element-major
+#endif
 #ifndef NRV_L2U_EXP
 #define NRV_L2U_EXP 0      // timing experiments (results WRONG): 1 no barrier in the exchange, 2 no gate arithmetic, 4 no matrix products
 #endif
@@ -73,10 +76,12 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
   for (int i = 0; i < 8; ++i) c[i] = 0.f;
 
   constexpr int GST = 13;
-  struct GateSt { float zi, zf, zg, zo, cp, p, t, hv[4]; };
-  GateSt gs;
+  struct GateSt { float zi, zf, zg, zo, cp, p, t; };
+  GateSt gsr[4];                                       // one per element of the unit tile in flight (stage-major order)
+  float hv[4];
   auto gate_stage = [&](int u, int r, int st, int t_out) __attribute__((always_inline)) {
     const int e = 4 * u + r;
+    GateSt& gs = gsr[NRV_L2U_ILP ? r : 0];
 #if NRV_L2U_EXP & 2
     if (st == 0) { hN[0][e] = (_Float16)Z[u][r]; hN[1][e] = (_Float16)Z[6 + u][r]; }
     return;
@@ -104,10 +109,10 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
       gs.zg = cn * 2.885390081777927f;
     } else if (st == 8) gs.zg = __builtin_amdgcn_exp2f(gs.zg);
     else if (st == 9) gs.t = __builtin_amdgcn_rcpf(gs.zg + 1.0f);
-    else if (st == 10) gs.hv[r] = gs.zo * __builtin_fmaf(gs.t, -2.0f * kHScale, kHScale);   // o tanh(c) 2^13
+    else if (st == 10) hv[r] = gs.zo * __builtin_fmaf(gs.t, -2.0f * kHScale, kHScale);   // o tanh(c) 2^13
     else if (st == 11) {
       if (r & 1) {
-        const f16x2 hp = __builtin_convertvector(f32x2{gs.hv[r - 1], gs.hv[r]}, f16x2);
+        const f16x2 hp = __builtin_convertvector(f32x2{hv[r - 1], hv[r]}, f16x2);
         hN[0][4 * u + r - 1] = hp[0];
         hN[0][4 * u + r] = hp[1];
       }
@@ -115,7 +120,7 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
       if (r & 1) {
         const int j = 4 * u + r;
         const f16x2 lp = __builtin_convertvector(
-            f32x2{gs.hv[r - 1] - (float)hN[0][j - 1], gs.hv[r] - (float)hN[0][j]}, f16x2);
+            f32x2{hv[r - 1] - (float)hN[0][j - 1], hv[r] - (float)hN[0][j]}, f16x2);
         hN[1][j - 1] = lp[0];
         hN[1][j] = lp[1];
       }
@@ -129,12 +134,17 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
       }
     }
   };
+  // piece pc (0 .. 4 GST - 1) of a unit tile: stage-major (pc = 4 st + r: the four elements' stages are independent neighbours, a
+  // dependent instruction is four pieces away) or element-major (pc = GST r + st: lstm2_t_kernel's order, one wave per SIMD)
+  auto gate_piece = [&](int u, int pc, int t_out) __attribute__((always_inline)) {
+    if (NRV_L2U_ILP) gate_stage(u, pc & 3, pc >> 2, t_out);
+    else gate_stage(u, pc / GST, pc % GST, t_out);
+  };
   auto gates_plain = [&](int u, int t_out) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int st = 0; st < GST; ++st) gate_stage(u, r, st, t_out);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int pc = 0; pc < 4 * GST; ++pc) {
+      gate_piece(u, pc, t_out);
+      if ((pc & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   };
   constexpr int NGP = 4 * GST;                         // stage pieces of one unit tile
@@ -158,7 +168,7 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
         if (u > 0) {
           const int tk = (ci & 7) * 3 + pr;             // tick inside this unit tile: 0..23
 #pragma unroll
-          for (int pc = (tk * NGP) / 24; pc < ((tk + 1) * NGP) / 24; ++pc) gate_stage(0, pc / GST, pc % GST, t_out);
+          for (int pc = (tk * NGP) / 24; pc < ((tk + 1) * NGP) / 24; ++pc) gate_piece(0, pc, t_out);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -192,7 +202,7 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
           const int tk = k * 3 + pr;                    // 0..23; the gates of unit tile 1 take ticks 0..11
           if (tk < 12) {
 #pragma unroll
-            for (int pc = (tk * NGP) / 12; pc < ((tk + 1) * NGP) / 12; ++pc) gate_stage(1, pc / GST, pc % GST, t_out);
+            for (int pc = (tk * NGP) / 12; pc < ((tk + 1) * NGP) / 12; ++pc) gate_piece(1, pc, t_out);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
