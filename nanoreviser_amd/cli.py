@@ -77,9 +77,10 @@ def get_args(argv: Optional[Sequence[str]] = None):
     p.add_argument("--resume", action="store_true", default=False,
                    help="skip every read whose <stem>_out.<format> already exists and is not empty (outputs are written "
                         "through a temporary + rename, so an existing file is a finished one)")
-    p.add_argument("--split_reads_above", type=float, default=float(os.environ.get("NRV_SPLIT_READS_MB", "16")),
-                   help="with more than one GPU: a fast5 file above this many MB (~10 MB per 100 k events) has its "
-                        "window range split over the GPU workers, T-1 events of halo per slice (0 = never)")
+    p.add_argument("--split_reads_above", type=float, default=float(os.environ.get("NRV_SPLIT_READS_MB", "4")),
+                   help="with more than one GPU: a fast5 file above this many MB (~10 MB per 100 k events) AND above a GPU "
+                        "worker's fair share of the input has its window range split over the workers, T-1 events of halo "
+                        "per slice (0 = never)")
     a = p.parse_args(argv)
     if a.virsion:
         print(f"The virsion of NanoReviser : {VERSION} ")
@@ -903,13 +904,16 @@ def share_device() -> bool:
 
 
 def plan_splits(names: Sequence[str], sizes: Sequence[int], world: int, split_mb: float):
-    """Which files are revised whole and which by window range: a fast5 above `split_mb` MB is cut into
-    min(world, ceil(size / split_mb)) slices (file size is the only thing known before parsing: ~100 bytes per event).
-    Returns (units, unit_sizes): a unit is a file name or (file name, slice, slices)."""
+    """Which files are revised whole and which by window range.  A fast5 is split only when it would unbalance the run - it is
+    larger than a worker's fair share of all bytes - and is worth it (above `split_mb` MB: every worker that holds a slice parses
+    the whole file, ~3 ms per MB); it is cut into min(world, ceil(size / max(fair share, split_mb))) slices.  File size is the only
+    thing known before parsing (~100 bytes per event).  Returns (units, unit_sizes): a unit is a file name or (file name, slice, slices)."""
     units, usz = [], []
     lim = int(split_mb * (1 << 20)) if split_mb and split_mb > 0 else 0
+    fair = sum(int(x) for x in sizes) / max(1, world)
+    cut = max(lim, int(fair))
     for fn, sz in zip(names, sizes):
-        parts = min(world, -(-int(sz) // lim)) if lim and world > 1 and sz > lim else 1
+        parts = min(world, -(-int(sz) // cut)) if lim and world > 1 and sz > cut else 1
         if parts <= 1:
             units.append(fn)
             usz.append(int(sz))

@@ -214,12 +214,18 @@ def test_long_read_is_split_over_the_gpu_workers_with_a_halo(tmp_path, fmt):
     """BASELINE config 5 / SURVEY 8e: a read too long for one worker's share is cut by WINDOW RANGE, T-1 events of halo
     (shard.split_read_windows), every slice revised by another worker process, the parent merges.  The engine's calls
     depend on the centre event (deletions, insertions, disagreements included), so the files equal the unsplit run's
-    byte for byte only if the slices tile the read exactly.  Threshold 0.2 MB: the 0.7-0.9 MB fixtures become 3 slices."""
+    byte for byte only if the slices tile the read exactly.  Threshold 0.2 MB, three workers: each 0.7-0.9 MB fixture is above
+    the fair share (0.53 MB) and becomes two slices."""
     one, three = str(tmp_path) + "/one/", str(tmp_path) + "/three/"
     assert cli.main(["-d", FAST5, "-o", one, "-S", "ecoli", "-F", fmt, "--thread", "1"], reviser_factory=lambda a, dev: HashEngine()) == 0
     units, _ = cli.plan_splits(["a", "b"], [900_000, 100_000], 3, 0.2)
-    assert units == [("a", 0, 3), ("a", 1, 3), ("a", 2, 3), "b"]
+    assert units == [("a", 0, 3), ("a", 1, 3), ("a", 2, 3), "b"]            # 0.9 MB against a fair share of 0.33 MB
     assert cli.plan_splits(["a"], [900_000], 1, 0.2)[0] == ["a"] and cli.plan_splits(["a"], [900_000], 8, 0)[0] == ["a"]
+    # a long read among many: it does not unbalance anything, and every slice would cost another parse of the file
+    many = cli.plan_splits(["big"] + [f"r{i}" for i in range(400)], [40 << 20] + [800_000] * 400, 8, 4)[0]
+    assert many[0] == "big" and len(many) == 401
+    # three long reads on eight GPUs: each above its fair share (37.5 MB) -> 3 slices each
+    assert [u for u in cli.plan_splits(["x", "y", "z"], [100 << 20] * 3, 8, 4)[0] if u[0] == "x"] == [("x", k, 3) for k in range(3)]
     assert cli.main(["-d", FAST5, "-o", three, "-S", "ecoli", "-F", fmt, "--thread", "1", "--split_reads_above", "0.2"],
                     worker_factory=hash_factory, world=3) == 0
     names = sorted(f for f in os.listdir(one) if f.endswith("_out." + fmt))
@@ -232,8 +238,11 @@ def test_long_read_is_split_over_the_gpu_workers_with_a_halo(tmp_path, fmt):
     assert open(three + "failed_reads.txt").read() == ""
 
 
-def test_split_read_whose_worker_dies_gets_its_original_bases(tmp_path):
+def test_split_read_whose_worker_dies_gets_its_original_bases(tmp_path, monkeypatch):
     out = str(tmp_path) + "/o/"
+    monkeypatch.setattr(cli, "plan_splits", lambda names, sizes, world, mb: (
+        [(names[0], 0, 2), (names[0], 1, 2), (names[1], 0, 2), (names[1], 1, 2)], [1, 1, 1, 1]))
+    monkeypatch.setattr(cli, "shard_reads", lambda sizes, world: [[0, 2], [1, 3]])     # worker 1 (the one that dies) holds a slice of each
     rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1", "--split_reads_above", "0.4"],
                   worker_factory=hash_dies_on_slice_factory, world=2)
     assert rc == 3
