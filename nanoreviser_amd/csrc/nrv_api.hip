@@ -1567,8 +1567,7 @@ struct HostPin {
     on = true;
     return true;
   }
-  void release() { this->~HostPin(); on = false; }
-  ~HostPin() {
+  void release() {
     if (!on) return;
     if (!settled) {                             // error paths: no DMA of THIS handle may still be reading the range
       (void)hipStreamSynchronize(owner->copy_stream);
@@ -1576,7 +1575,9 @@ struct HostPin {
       (void)hipStreamSynchronize(owner->d2h_stream);
     }
     (void)hipHostUnregister(p);
+    on = false;
   }
+  ~HostPin() { release(); }
 };
 
 static int grow_pinned(nrv_handle* h, char* (&buf)[nrv_handle::kIn], size_t* cap, size_t need) {
