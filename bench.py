@@ -968,7 +968,7 @@ def helper_main():
             break
         try:
             if cmd.get("cmd") == "cli":
-                res = cli_e2e(cmd.get("reps", 2000), cmd.get("threads", 16), cmd.get("gpus", 1), cmd.get("share", False))
+                res = cli_e2e(cmd.get("reps", 4000), cmd.get("threads", 16), cmd.get("gpus", 1), cmd.get("share", False))
             elif cmd.get("cmd") == "hostcap":
                 res = host_capacity(int(cmd.get("cores", 1)), float(cmd.get("min_s", 2.0)))
             else:
@@ -1229,7 +1229,7 @@ def main(argv=None):
     ap.add_argument("--share-device", action="store_true",
                     help="rank r runs on device r %% device_count (rehearse N ranks on fewer GPUs; never the default)")
     ap.add_argument("--no-cli-e2e", action="store_true", help="skip host_inclusive.cli_e2e (the CLI in a child process)")
-    ap.add_argument("--cli-reps", type=int, default=2000, help="cli_e2e: copies of each committed fixture read")
+    ap.add_argument("--cli-reps", type=int, default=4000, help="cli_e2e: copies of each committed fixture read (x N with --gpus N)")
     ap.add_argument("--hostcap-seconds", type=float, default=2.0, help="cpu_baseline.host_capacity: seconds per point")
     ap.add_argument("--helper", action="store_true", help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
