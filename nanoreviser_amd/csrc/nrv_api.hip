@@ -472,6 +472,7 @@ struct DevModel {
   size_t cr_dbias = 0;                   // cnn_r_kernel: dense bias x 2^16
   size_t cr_w2 = 0, cr_ep = 0, cr_d = 0; // cnn_r_kernel: conv2 in its two-position form, epilogue constants, dense A fragments
   size_t cr_c1 = 0;                      // cnn_r_kernel: conv1 as a matrix product: per-lane A operand, bias, BatchNorm 1
+  size_t fw8 = 0;                        // head_h2_kernel: feature kernel as its LDS image [16][T][8]
   CnnRConsts cr_k;                       // ... and the first convolution's constants (kernel arguments)
   size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
   HeadH2Scales hsc;
@@ -787,6 +788,16 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
   d.h_ws = put(wp.data(), wp.size());
   d.h_wb = put(bs.data(), bs.size());
   d.fw = put(b.t(56), (size_t)6 * T * 16);
+  {
+    // head_h2_kernel's LDS image of the feature kernel, [f 16][t][8] (k padded 6 -> 8), packed here: the kernel built it itself
+    // until r05 (four dependent scalar-indexed loads + two integer divisions per thread in front of its first barrier)
+    std::vector<float> f8((size_t)16 * T * 8, 0.f);
+    const float* fwp = b.t(56);
+    NRV_FOR (int f = 0; f < 16; ++f)
+      NRV_FOR (int t = 0; t < T; ++t)
+        NRV_FOR (int k = 0; k < 6; ++k) f8[((size_t)f * T + t) * 8 + k] = fwp[(size_t)(t * 6 + k) * 16 + f];
+    d.fw8 = put(f8.data(), f8.size());
+  }
   d.fb = put(b.t(57), 16);
   d.ow = put(b.t(58), (size_t)16 * C);
   d.ob = put(b.t(59), C);
@@ -1237,7 +1248,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       ha.T = T; ha.n_rows = n; ha.n_tiles = tiles;
       for (int m = 0; m < 2; ++m) {
         const DevModel& d = h->dm[m];
-        ha.m[m] = HeadH2ModelParams{d.all + d.h_w2, d.all + d.h_b2, h->X2[m], d.all + d.fw, d.all + d.fb, d.all + d.ow,
+        ha.m[m] = HeadH2ModelParams{d.all + d.h_w2, d.all + d.h_b2, h->X2[m], d.all + d.fw8, d.all + d.fb, d.all + d.ow,
                                     d.all + d.ob, dp[m], da[m], d.hsc.c12, d.hsc.c23, d.hsc.c3o, d.C};
       }
       if (NRV_RUN_STAGE(5)) hipLaunchKernelGGL(head_h2_kernel, dim3(tiles < 128 ? tiles : 128, 2), dim3(kHeadH2Threads), 0, h->stream, ha);

@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
       for (int j = 0; j < 8; ++j)
         if (base + j * kCnnRThreads + threadIdx.x < NKS * 8 * 64) ((f32x4*)wd_s)[base + j * kCnnRThreads + threadIdx.x] = v[j];
     }
-    for (int i = threadIdx.x; i < kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot; i += kCnnRThreads) c1_s[i] = (_Float16)0.f;   // incl. the zero slot
+    static_assert((kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot) % 8 == 0, "ring image in 16-byte pieces");
+    for (int i = threadIdx.x; i < (kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot) / 8; i += kCnnRThreads) ((f32x4*)c1_s)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // incl. the zero slot
   }
   __syncthreads();                                   // the only barrier: from here on the waves are independent
 

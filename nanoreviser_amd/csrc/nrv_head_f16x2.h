@@ -27,7 +27,7 @@ struct HeadH2ModelParams {
   const void* wsplit;     // [84 fragments][64 lanes][8 f16]: dense1 [mt 4][kb 8][term 2], dense2 [kb 8][term 2], main_out [kb 2][term 2]
   const float* bias;      // [128 | 32 | 32], each x 2^E of its layer (main_out padded with zeros)
   const float* in;        // 256->64 Bi-LSTM output as f16 split planes (32 chunks per (tile, t))
-  const float* featw;     // [6T][16]
+  const float* featw;     // the feature kernel as the LDS image [16][T][8] (k padded 6 -> 8), packed by upload_model
   const float* featb;     // [16]
   const float* outw;      // [16][C]
   const float* outb;      // [C]
@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
   __shared__ __attribute__((aligned(16))) float fw8[16 * TMAX * 8];       // feature kernel [f][t][8] (k padded to 8)
   __shared__ float featv[32 * 17];
   __shared__ float logit[32 * 8];
+  __shared__ float tl[16 + 8 + 16 * 8];                                   // the tail's constants: featb 16, outb 8, outw [16][C]
   const HeadH2ModelParams& P = args.m[blockIdx.y];
   const int T = args.T;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -72,10 +73,14 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
     }
   }
   if (tid < 192) bl[tid] = P.bias[tid];
-  for (int i = tid; i < 16 * T * 8; i += NT) {
-    const int f = i / (T * 8), t = (i / 8) % T, k = i & 7;
-    fw8[i] = k < 6 ? P.featw[(t * 6 + k) * 16 + f] : 0.f;
+  {
+    // the per-window tail's constants too (r05: its 16 + 1 + 16 global loads per thread sat between two barriers at the very end)
+    const int C0 = P.n_class;
+    if (tid >= 256 && tid < 272) tl[tid - 256] = P.featb[tid - 256];
+    else if (tid >= 272 && tid < 280) tl[tid - 256] = tid - 272 < C0 ? P.outb[tid - 272] : 0.f;
+    else if (tid >= 320 && tid < 320 + 16 * C0) tl[24 + tid - 320] = P.outw[tid - 320];
   }
+  for (int i = tid; i < 16 * T * 2; i += NT) ((f32x4*)fw8)[i] = ((const f32x4*)P.featw)[i];   // one 16-byte copy per thread at T <= 16
   __syncthreads();
 
   const float m1 = neg_one_opaque();
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
     // ---- per-window tail of this tile: Flatten(6T) -> Dense(16,relu) -> Dense(C,softmax) -> argmax
     for (int it = tid; it < 32 * 16; it += NT) {
       const int r = it >> 4, f = it & 15;
-      float v = P.featb[f];
+      float v = tl[f];
       for (int t = 0; t < T; ++t) {
         const f32x4 x0 = *(const f32x4*)(mo + (t * 32 + r) * 8), x1 = *(const f32x4*)(mo + (t * 32 + r) * 8 + 4);
         const f32x4 w0 = *(const f32x4*)(fw8 + (f * T + t) * 8), w1 = *(const f32x4*)(fw8 + (f * T + t) * 8 + 4);
@@ -190,9 +195,9 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
     if (tid < 256) {
       const int r = tid >> 3, cc = tid & 7;
       if (cc < C) {
-        float v = P.outb[cc];
+        float v = tl[16 + cc];
 #pragma unroll
-        for (int f = 0; f < 16; ++f) v = __builtin_fmaf(featv[r * 17 + f], P.outw[f * C + cc], v);
+        for (int f = 0; f < 16; ++f) v = __builtin_fmaf(featv[r * 17 + f], tl[24 + f * C + cc], v);
         logit[r * 8 + cc] = v;
       }
     }
