@@ -87,3 +87,38 @@ def test_blas_grade_cpu_baseline_is_the_same_graph(species_models):
     sig, rd = O.synth_windows(64, 11)
     r = bench.blas_grade_baseline(m1, m2, 11, sig, rd, 2, 0.5)
     assert r.get("value", 0) > 0 and r["dtype"] == "f32" and r["cores"] == 2, r
+
+
+def test_roofline_block_carries_mfma_utilisation_and_hbm_rate(tmp_path, monkeypatch):
+    """north_star: "rocprof HBM GB/s and MFMA utilisation reported against gfx950 peak" - the JSON line takes them from the
+    committed PMC record of the kernel it times, and prints null (with the reason) when that record is stale."""
+    import argparse
+    m = {"prof": {"cnn": (0.0, 0), "lstm1": (0.0, 0), "lstm2": (0.0, 0), "lstm3 192->128": (1.45, 10), "lstm4": (0.0, 0), "head": (0.0, 0)},
+         "kernel_us": {"lstm3 192->128": 150.0}, "prof_mode": 3, "bracket_overhead_us": 5.0, "ms_per_step": 0.32}
+    args = argparse.Namespace()
+    rec = {"T": 13, "batch": 4096, "kernel_name": "void nrv::" + bench.KERNEL_SIGNATURE["f16x2"] + "(nrv::LstmH2Args)",
+           "source_sha256_16": bench.kernel_source_sha("f16x2"), "commit": "abc", "hbm_bytes_per_launch": 2.88e8, "source": "t",
+           "mfma_busy_frac": 0.68, "traffic_step": 7.6e8, "traffic_step_by_kernel": {"lstm3": 2.88e8},
+           "step_source_sha256_16": bench.step_source_sha()}
+    good = (rec["hbm_bytes_per_launch"], "x", rec)
+    monkeypatch.setattr(bench, "load_traffic", lambda T, B, prec, d=None: good)
+    r = bench.roofline_blocks(args, 13, 4096, "f16x2", m)["roofline"]
+    assert abs(r["avg_launch_us"] - 140.0) < 1e-6                              # 145 us bracketed - 5 us of empty bracket
+    assert abs(r["hbm_gbps"] - 2.88e8 / 140e-6 / 1e9) < 1e-6 and abs(r["hbm_frac_of_peak"] - r["hbm_gbps"] / 8000) < 1e-9
+    assert r["mfma_busy_frac"] == 0.68 and r["traffic_step"] == 7.6e8 and "12" in r["traffic_step_note"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["frac"] < 1
+    stale = dict(rec, step_source_sha256_16="0" * 16)
+    monkeypatch.setattr(bench, "load_traffic", lambda T, B, prec, d=None: (rec["hbm_bytes_per_launch"], "x", stale))
+    r = bench.roofline_blocks(args, 13, 4096, "f16x2", m)["roofline"]
+    assert r["traffic_step"] is None and "another version" in r["traffic_step_note"] and r["hbm_gbps"] is not None
+    monkeypatch.setattr(bench, "load_traffic", lambda T, B, prec, d=None: (None, "no committed PMC pass", {}))
+    r = bench.roofline_blocks(args, 13, 4096, "f16x2", m)["roofline"]
+    assert r["traffic"] is None and r["hbm_gbps"] is None and r["mfma_busy_frac"] is None and r["traffic_step"] is None
+
+
+def test_scratch_base_prefers_a_tmpfs_and_can_be_overridden(monkeypatch, tmp_path):
+    monkeypatch.setenv("NRV_BENCH_SCRATCH", str(tmp_path))
+    assert bench.scratch_base() == (str(tmp_path), "NRV_BENCH_SCRATCH")
+    monkeypatch.delenv("NRV_BENCH_SCRATCH")
+    base, what = bench.scratch_base()
+    assert (base == "/dev/shm" and "tmpfs" in what) or (base is None and "default temporary directory" in what)
