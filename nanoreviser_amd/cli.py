@@ -970,17 +970,23 @@ def _worker(rank: int, world: int, args, files: List[str], q, factory=None, part
                 share = max(1, min(len(cpus), cores_all // max(1, world)))
             except OSError:
                 cpus = None
-        rv = (factory or _default_factory)(args, device)
+        made = []
+
+        def make():                                   # one engine per call; process_files may call it from its engine thread
+            made.append((factory or _default_factory)(args, device))
+            return made[-1]
+        rv = make() if parts else None                # slices need the engine now; whole files let it come up beside the parsers
         for fn, k, n in parts:
             try:
                 payload, err = revise_part(args, rv, fn, k, n)
             except Exception as e:
                 payload, err = None, repr(e)
             q.put(("part", rank, fn, k, payload, err))
-        st = process_files(args, files, rv, print, on_file=lambda fn, ok: q.put(("file", rank, fn, bool(ok))),
-                           gpu_workers=world, core_share=share)
+        st = process_files(args, files, rv if rv is not None else make, print,
+                           on_file=lambda fn, ok: q.put(("file", rank, fn, bool(ok))), gpu_workers=world, core_share=share)
         st["cpus"] = len(cpus) if cpus else 0
-        rv.close()
+        for e in made:
+            e.close()
         q.put(("done", rank, st, None))
     except BaseException as e:           # engine could not be created: loud, no silent fallback
         q.put(("done", rank, None, repr(e)))
