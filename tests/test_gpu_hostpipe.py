@@ -1,0 +1,67 @@
+"""The host-pointer pipeline of nrv_predict over MANY stages (MI355X only, -m gpu): three input staging sets in rotation, two
+output sets, uploads one stage ahead, one download per stage (csrc/nrv_api.hip predict_host, r05).  Results do not depend on
+the grouping, so a call of seven stages must give, window for window, the bits of one-stage calls on the same windows -
+with the caller's arrays registered in place AND through the bounce buffers (NRV_HOST_REGISTER=0) - and a stage that trips
+the f16x2 range guard late in the call (its inputs must still be in their staging set) must come back with the f32 kernels'
+bits while its neighbours keep theirs."""
+import os
+
+import numpy as np
+import pytest
+
+from nanoreviser_amd import hoststage as hs
+
+pytestmark = pytest.mark.gpu
+
+
+def _seven_stages(reads, T=11):
+    _, _, rt = reads("ch13_read2251")
+    sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, T)
+    n = 6 * 4096 + 1234                                            # seven stages, the last one ragged
+    idx = np.arange(n) % (len(fw) - 7)                             # the read's windows, wrapped around
+    idx = (idx * 7919) % (len(fw) - 7)                             # ... and shuffled: every stage holds different windows
+    return np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx])
+
+
+@pytest.mark.parametrize("register", ["1", "0"])
+def test_seven_stage_call_equals_one_stage_calls(reads, species_models, register, monkeypatch):
+    from nanoreviser_amd.engine import Reviser
+    monkeypatch.setenv("NRV_HOST_REGISTER", register)              # read at nrv_create
+    m1, m2 = species_models["ecoli"]
+    sw, fw = _seven_stages(reads)
+    rv = Reviser(m1, m2, precision="f16x2")
+    whole = rv.predict_pair(sw, fw)
+    for s in (0, 3, 5, 6):                                         # stages 0, 3 (first reuse of input set 0), 5, the ragged last
+        lo, hi = s * 4096, min((s + 1) * 4096, len(fw))
+        part = rv.predict_pair(np.ascontiguousarray(sw[lo:hi]), np.ascontiguousarray(fw[lo:hi]))
+        for w, p in zip(whole, part):
+            assert np.array_equal(w[lo:hi].view(np.uint8), p.view(np.uint8)), (register, s)
+    again = rv.predict_pair(sw, fw)                                # and the call is repeatable on one handle
+    assert all(np.array_equal(a, b) for a, b in zip(whole, again))
+    assert rv.saturated() == (0, 0)
+    rv.close()
+
+
+def test_late_stage_range_rerun_keeps_its_inputs(reads, species_models):
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["human"]
+    sw, fw = _seven_stages(reads)
+    clean = sw.copy()
+    rng = np.random.default_rng(11)
+    for stage in (4, 6):                                           # spikes in stage 4 (input set 1, second use) and in the last
+        lo = stage * 4096
+        for w in lo + rng.choice(min(4096, len(fw) - lo), 25, replace=False):
+            sw[w, rng.integers(11), rng.integers(50)] *= np.float32(2000.0)
+    rv = Reviser(m1, m2, precision="f16x2")
+    base = rv.predict_pair(clean, fw)
+    assert rv.saturated() == (0, 0)
+    got = rv.predict_pair(sw, fw)
+    assert rv.saturated() == (0, 2)                                # exactly the two spiked stages were re-run
+    rv.set_precision("f32")
+    ref32 = rv.predict_pair(sw, fw)
+    rv.close()
+    for g, b, r in zip(got, base, ref32):
+        for stage in range(7):
+            lo, hi = stage * 4096, min((stage + 1) * 4096, len(fw))
+            want = r if stage in (4, 6) else b
+            assert np.array_equal(g[lo:hi].view(np.uint8), want[lo:hi].view(np.uint8)), stage
