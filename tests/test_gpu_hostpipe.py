@@ -65,3 +65,26 @@ def test_late_stage_range_rerun_keeps_its_inputs(reads, species_models):
             lo, hi = stage * 4096, min((stage + 1) * 4096, len(fw))
             want = r if stage in (4, 6) else b
             assert np.array_equal(g[lo:hi].view(np.uint8), want[lo:hi].view(np.uint8)), stage
+
+
+def test_raw_read_call_of_five_stages_equals_shorter_calls(species_models):
+    """Read mode (device-formed windows, 16384 windows per stage): the five fixture reads twice in one call = five stages; window i
+    of the concatenation depends on events i .. i + T - 1 only, so both halves must carry the bits of the five-read call."""
+    import bench
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["human"]
+    reads = bench.fixture_reads()
+
+    def pack(rs):
+        return [[r.raw for r in rs], [r.starts for r in rs], [r.feat_ev for r in rs], [r.shift for r in rs], [r.scale for r in rs]]
+    rv = Reviser(m1, m2, precision="f16x2")
+    five = rv.predict_reads_raw(*pack(reads))
+    ten = rv.predict_reads_raw(*pack(reads + reads))
+    N5 = sum(len(r.feat_ev) for r in reads)
+    n5 = N5 - rv.T
+    assert len(ten[2]) == 2 * N5 - rv.T and len(five[2]) == n5 and n5 > 2 * 16384
+    for t, f in zip(ten, five):
+        assert np.array_equal(t[:n5].view(np.uint8), f.view(np.uint8))
+        assert np.array_equal(t[N5:N5 + n5].view(np.uint8), f.view(np.uint8))
+    assert rv.saturated() == (0, 0)
+    rv.close()
