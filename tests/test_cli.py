@@ -252,6 +252,52 @@ def test_split_read_whose_worker_dies_gets_its_original_bases(tmp_path, monkeypa
         assert open(out + fn.split(".")[0] + "_out.fasta").read() == ">" + fn + "\n" + _orig(fn)
 
 
+def test_split_read_slices_that_do_not_tile_fall_back_to_the_original(tmp_path):
+    """Parent side of a split read (cli.finish_split_reads): slices are merged only when they tile the read exactly - same event
+    count and window length from every worker, each slice where shard.split_read_windows puts it, slice 0 carrying the bases; a
+    missing, failed or misplaced slice gives the original basecalls and a failed-reads entry (NanoReviser.py:146-152)."""
+    from nanoreviser_amd.shard import split_read_windows
+    fn = sorted(os.listdir(FAST5))[0]
+    rd, _ = cli.parse_read(os.path.join(FAST5, fn), "Basecall_1D_000", "BaseCalled_template")
+    rt = hs.read_tensors_raw(rd)
+    N, T = len(rt.feat_ev), 11
+    eng = HashEngine()
+    whole = eng.predict_reads_raw([rt.raw], [rt.starts], [rt.feat_ev], [rt.shift], [rt.scale])
+
+    def parts(n, tamper=None):
+        got = {}
+        for k, (lo, hi) in enumerate(split_read_windows(N, T, n)):
+            a1, a2 = whole[2][lo:hi - T], whole[3][lo:hi - T]
+            pl = {"T": T, "n_ev": N, "lo": lo, "a1": a1, "a2": a2, "qc": None}
+            if k == 0:
+                pl["bases"], pl["fq"] = np.asarray(rt.bases), None
+            got[k] = (pl, None)
+        if tamper:
+            tamper(got)
+        return {fn: got}
+    logs = []
+
+    def run(tag, got, n=3):
+        args = cli.get_args(["-d", FAST5 + "/", "-o", str(tmp_path / tag) + "/", "-S", "ecoli"])
+        nb, failed = cli.finish_split_reads(args, {fn: n}, got, logs.append)
+        return nb, failed, open(cli.out_name(args.output_dir, fn, "fasta")).read().split("\n", 1)[1]
+    one = str(tmp_path / "one") + "/"
+    assert cli.main(["-d", FAST5, "-o", one, "-S", "ecoli", "--thread", "1"], reviser_factory=lambda a, d: HashEngine()) == 0
+    want = open(cli.out_name(one, fn, "fasta")).read().split("\n", 1)[1]
+    nb, failed, text = run("ok", parts(3))
+    assert failed == [] and text == want and nb == len(want)
+    orig = _orig(fn)
+    for tag, tamper in (("missing", lambda g: g.pop(1)),
+                        ("failed", lambda g: g.__setitem__(2, (None, "engine error"))),
+                        ("shifted", lambda g: g[1][0].__setitem__("lo", g[1][0]["lo"] + 1)),
+                        ("short", lambda g: g[2][0].__setitem__("a1", g[2][0]["a1"][:-1])),
+                        ("other_T", lambda g: g[1][0].__setitem__("T", 13)),
+                        ("no_bases", lambda g: g[0][0].pop("bases"))):
+        nb, failed, text = run(tag, parts(3, tamper))
+        assert failed == [fn] and nb == 0 and text == orig, tag
+    assert sum("writing the original basecalls" in m for m in logs) == 6
+
+
 def _fake_sysfs(root, gpus):
     """gpus: [(domain, bus, numa cpulist)] -> a /sys tree with a CPU node 0 and one KFD node per GPU."""
     nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
