@@ -33,7 +33,13 @@ typedef struct {
   const uint8_t* d;
   size_t n;
   int bad;          /* set by any out-of-range access: the file is truncated / not what we parse */
+  uint64_t work;    /* tree nodes / heap objects visited: a file whose links form a cycle runs out of budget, not of time */
 } Buf;
+#define WORK_BUDGET ((uint64_t)1 << 20)
+static int spend(Buf* b) {
+  if (++b->work > WORK_BUDGET) { b->bad = 1; return -1; }
+  return 0;
+}
 
 static uint64_t U(Buf* b, uint64_t off, int nb) {
   if (off > b->n || (uint64_t)nb > b->n - off) { b->bad = 1; return 0; }
@@ -81,7 +87,7 @@ static const Msg* find_msg(const Obj* o, int type) {
 /* ---- groups: symbol table -> v1 B-tree -> SNOD -> local heap -------------------------------------------------- */
 /* name == NULL: the FIRST link in B-tree order is taken (h5lite: reads.keys()[0]) */
 static int walk_group(Buf* b, uint64_t node, uint64_t hdata, const char* name, uint64_t* found, int depth) {
-  if (depth > 16 || b->bad) return -1;
+  if (depth > 16 || b->bad || spend(b)) return -1;
   const uint8_t* sig = P(b, node, 8);
   if (!sig) return -1;
   if (!memcmp(sig, "TREE", 4)) {
@@ -141,7 +147,12 @@ typedef struct { int cls, size, is_signed; } Prim;     /* cls: 0 fixed point, 1 
 typedef struct { char name[32]; int off; Prim t; } Member;
 
 /* one datatype message at `off`: returns bytes consumed (>0) or -1.  Big-endian numbers -> -1 (never seen). */
+static int64_t parse_type_d(Buf* b, uint64_t off, Prim* pt, Member* mem, int* nmem, int max_mem, int* total_size, int depth);
 static int64_t parse_type(Buf* b, uint64_t off, Prim* pt, Member* mem, int* nmem, int max_mem, int* total_size) {
+  return parse_type_d(b, off, pt, mem, nmem, max_mem, total_size, 0);
+}
+static int64_t parse_type_d(Buf* b, uint64_t off, Prim* pt, Member* mem, int* nmem, int max_mem, int* total_size, int depth) {
+  if (depth > 4) return -1;                             /* vlen of vlen of ...: one level is all a fast5 has */
   const int cv = (int)U(b, off, 1), cls = cv & 15, ver = cv >> 4;
   const uint32_t bits = (uint32_t)U(b, off + 1, 3);
   const int size = (int)U(b, off + 4, 4);
@@ -154,7 +165,7 @@ static int64_t parse_type(Buf* b, uint64_t off, Prim* pt, Member* mem, int* nmem
   if (cls == 9) {                                       /* variable length: only strings (global heap), for attributes */
     if ((bits & 15) != 1) return -1;
     Prim base;
-    const int64_t used = parse_type(b, p, &base, 0, 0, 0, 0);
+    const int64_t used = parse_type_d(b, p, &base, 0, 0, 0, 0, depth + 1);
     if (used < 0) return -1;
     pt->cls = 9; pt->size = size; pt->is_signed = 0;
     return (int64_t)(p + (uint64_t)used - off);
@@ -180,7 +191,7 @@ static int64_t parse_type(Buf* b, uint64_t off, Prim* pt, Member* mem, int* nmem
         m.off = (int)U(b, p, nb); p += nb;
       }
       Prim sub;
-      const int64_t used = parse_type(b, p, &sub, 0, 0, 0, 0);
+      const int64_t used = parse_type_d(b, p, &sub, 0, 0, 0, 0, depth + 1);
       if (used < 0) return -1;                          /* nested compound / vlen / ... : not ours */
       p += (uint64_t)used;
       m.t = sub;
@@ -302,7 +313,7 @@ static int inflate_into(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, 
 /* the chunks of a 1-D chunked dataset into out[n_el * esize] */
 static int walk_chunks(Buf* b, const Dset* ds, uint64_t node, uint8_t* out, uint8_t* tmp, uint8_t* tmp2, int depth) {
   if (node == UNDEF_ADDR) return 0;
-  if (depth > 16) return -1;
+  if (depth > 16 || spend(b)) return -1;
   const uint8_t* sig = P(b, node, 24);
   if (!sig || memcmp(sig, "TREE", 4) || U(b, node + 4, 1) != 1) return -1;
   const int level = (int)U(b, node + 5, 1), used = (int)U(b, node + 6, 2);
@@ -358,7 +369,9 @@ static int dset_bytes(Buf* b, const Dset* ds, const uint8_t** out, size_t* nbyte
     *out = p; *nbytes = (size_t)want;
     return 0;
   }
-  if (ds->rank != 1 || ds->cdim == 0 || want > ((uint64_t)1 << 34)) return -1;
+  /* deflate expands at most ~1032 : 1, so a dataset cannot be larger than that many times the file; a chunk is never 2 GB */
+  if (ds->rank != 1 || ds->cdim == 0 || want > ((uint64_t)1 << 34) || want / 1032 > (uint64_t)b->n + 4096) return -1;
+  if ((uint64_t)ds->cdim * (uint64_t)ds->esize > ((uint64_t)1 << 31)) return -1;
   const size_t need = (size_t)ds->cdim * (size_t)ds->esize;
   uint8_t* buf = (uint8_t*)calloc((size_t)want + 1, 1);
   uint8_t* tmp = (uint8_t*)malloc(2 * need + 16);
@@ -401,7 +414,7 @@ static int version_is_new(Buf* b, uint64_t gaddr) {
       const uint64_t gend = gcol + U(b, gcol + 8, 8);
       uint64_t q = gcol + 16;
       int hit = 0;
-      while (q + 16 <= gend && !b->bad) {
+      while (q + 16 <= gend && !b->bad && !spend(b)) {
         const uint64_t oi = U(b, q, 2), osz = U(b, q + 8, 8);
         if (oi == 0) break;
         if (oi == idx) {
@@ -423,6 +436,7 @@ static int version_is_new(Buf* b, uint64_t gaddr) {
   return 0;                                             /* no attribute: h5lite defaults to "0.0" = old */
 }
 
+#define START_LIM ((int64_t)1 << 40)
 static int int_size_ok(const Prim* t) { return t->size == 1 || t->size == 2 || t->size == 4 || t->size == 8; }
 static int64_t load_int(const uint8_t* p, const Prim* t) {       /* callers check int_size_ok first */
   uint64_t v = 0;
@@ -478,19 +492,11 @@ static int fail(char* err, int err_len, int code, const char* msg) {
   return code;
 }
 
-int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, int want_fastq, nrvh_read* out,
-                    char* err, int err_len) {
-  if (!path || !group || !subgroup || !out) return fail(err, err_len, NRVH_E_ARG, "bad arguments");
+/* the image of one file (fsz bytes, not modified, not kept) -> *out; the sanitizer driver (tools/hostfuzz) enters here */
+static int load_fast5_image(const uint8_t* file, long fsz, const char* group, const char* subgroup, int want_fastq,
+                            nrvh_read* out, char* err, int err_len) {
   memset(out, 0, sizeof *out);
-  FILE* fp = fopen(path, "rb");
-  if (!fp) return fail(err, err_len, NRVH_E_IO, "cannot open the file");
-  fseek(fp, 0, SEEK_END);
-  const long fsz = ftell(fp);
-  fseek(fp, 0, SEEK_SET);
-  uint8_t* file = fsz > 0 ? (uint8_t*)malloc((size_t)fsz) : 0;
-  if (!file || fread(file, 1, (size_t)fsz, fp) != (size_t)fsz) { fclose(fp); free(file); return fail(err, err_len, NRVH_E_IO, "cannot read the file"); }
-  fclose(fp);
-  Buf B = {file, (size_t)fsz, 0};
+  Buf B = {file, (size_t)fsz, 0, 0};
   Buf* b = &B;
   int rc = NRVH_UNSUPPORTED;
   const char* why = "not the HDF5 subset of the native reader";
@@ -557,11 +563,13 @@ int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, i
     out->bases = (char*)malloc((size_t)n + 1);
     if (!st64 || !len64 || !abm || !abs_ || !out->bases) { rc = NRVH_E_IO; why = "out of memory"; break; }
     int64_t k = 0;
+    int wild = 0;                                       /* a start no DAQ produces: differences of those would overflow */
     for (int64_t i = 0; i < n_ev_in; ++i) {
       const uint8_t* row = ev_bytes + i * es;
       const int64_t mv = load_int(row + m_move->off, &m_move->t);
       if (mv == 0) continue;
       const int64_t s = load_int(row + m_start->off, &m_start->t);
+      if (s < -START_LIM || s > START_LIM) { wild = 1; break; }
       float fm, fs;
       memcpy(&fm, row + m_mean->off, 4); memcpy(&fs, row + m_stdv->off, 4);
       const char* ms = (const char*)row + m_state->off;
@@ -572,6 +580,7 @@ int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, i
         st64[k] = s; out->bases[k] = ms[2]; abm[k] = fm; abs_[k] = fs; ++k;
       }
     }
+    if (wild) { rc = NRVH_UNSUPPORTED; why = "event starts outside the native reader's range"; break; }
     out->bases[n] = 0;
     for (int64_t i = 0; i + 1 < n; ++i) len64[i] = (double)(st64[i + 1] - st64[i]);
     len64[n - 1] = st64[n - 1] - st64[n - 2] < 5 ? 3.0 : 5.0;
@@ -591,8 +600,8 @@ int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, i
     memcpy(out->raw, sig_bytes + a0 * 2, (size_t)out->n_raw * 2);
     int mono = 1;
     for (int64_t i = 0; i < n; ++i) {
+      if (st64[i] < a0 || st64[i] - a0 >= ((int64_t)1 << 31)) { mono = 0; break; }
       out->starts[i] = (int32_t)(st64[i] - a0);
-      if (st64[i] < a0) mono = 0;
     }
     if (!mono) { rc = NRVH_UNSUPPORTED; why = "event starts not ascending"; break; }
     /* ---- shift / scale, per-base mean / std (preprocessing.py:100-101, 134-137) */
@@ -633,9 +642,25 @@ int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, i
   if (sig_owned) free((void*)sig_bytes);
   if (fq_owned) free((void*)fq_bytes);
   free(st64); free(len64); free(abm); free(abs_); free(mean); free(sd);
-  free(file);
   if (rc != NRVH_OK) { nrvh_free_read(out); return fail(err, err_len, rc, why); }
   return NRVH_OK;
+}
+
+int nrvh_load_fast5(const char* path, const char* group, const char* subgroup, int want_fastq, nrvh_read* out,
+                    char* err, int err_len) {
+  if (!path || !group || !subgroup || !out) return fail(err, err_len, NRVH_E_ARG, "bad arguments");
+  memset(out, 0, sizeof *out);
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(err, err_len, NRVH_E_IO, "cannot open the file");
+  fseek(fp, 0, SEEK_END);
+  const long fsz = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  uint8_t* file = fsz > 0 && fsz < ((long)1 << 36) ? (uint8_t*)malloc((size_t)fsz) : 0;     /* a directory reports LONG_MAX */
+  if (!file || fread(file, 1, (size_t)fsz, fp) != (size_t)fsz) { fclose(fp); free(file); return fail(err, err_len, NRVH_E_IO, "cannot read the file"); }
+  fclose(fp);
+  const int rc = load_fast5_image(file, fsz, group, subgroup, want_fastq, out, err, err_len);
+  free(file);
+  return rc;
 }
 
 /* ---- several files -> the arrays of ONE device call ------------------------------------------------------------------ */
