@@ -463,7 +463,10 @@ def _hostcap_worker(rank, world, din, names, out_dir, threads, barrier, q):
         from nanoreviser_amd import cli
         args = cli.get_args(["-d", din + "/", "-o", out_dir + "/", "-S", "ecoli", "--thread", str(threads)])
         os.makedirs(args.output_dir, exist_ok=True)
-        cpus = cli.worker_cpus(rank, world, [0] * world)
+        # worker r next to GPU r, as `NanoReviser.py --gpus 8` places it; on a box with fewer GPUs worker_cpus finds no NUMA
+        # node for the missing ones and cuts the allowed cores into `world` contiguous slices (all eight on GPU 0's
+        # node was a placement the command line never uses)
+        cpus = cli.worker_cpus(rank, world, list(range(world)))
         share = None
         if cpus:
             cores_all = cli.usable_cores()
@@ -472,13 +475,13 @@ def _hostcap_worker(rank, world, din, names, out_dir, threads, barrier, q):
         cli.process_files(args, names[:8], NullEngine(), lambda m: None, gpu_workers=world, core_share=share)   # warm
         barrier.wait(120)
         st = cli.process_files(args, names, NullEngine(), lambda m: None, gpu_workers=world, core_share=share)
-        q.put((rank, st["bases"], st["parser_workers"], None))
+        q.put((rank, st["bases"], st["parser_workers"], None, sorted(cpus) if cpus else None))
     except BaseException as e:
         try:
             barrier.abort()
         except Exception:
             pass
-        q.put((rank, 0, 0, repr(e)))
+        q.put((rank, 0, 0, repr(e), None))
 
 
 def host_capacity(cores, min_s=2.0, max_reads=24000):
@@ -551,10 +554,11 @@ def host_capacity(cores, min_s=2.0, max_reads=24000):
                 t0 = time.perf_counter()
                 res = [q.get(timeout=300) for _ in procs]
                 dt = time.perf_counter() - t0
-                errs = [e for _, _, _, e in res if e]
+                errs = [e for _, _, _, e, _ in res if e]
                 if errs:
                     return {"error": errs[0]}
-                return {"rate": sum(b for _, b, _, _ in res) / dt, "seconds": dt, "threads": sorted({t for _, _, t, _ in res})}
+                return {"rate": sum(b for _, b, _, _, _ in res) / dt, "seconds": dt, "threads": sorted({t for _, _, t, _, _ in res}),
+                        "placement": {str(r): (f"{c[0]}-{c[-1]} ({len(c)} cpus)" if c else "not pinned") for r, _, _, _, c in sorted(res)}}
             except Exception as e:
                 return {"error": repr(e)}
             finally:
@@ -570,7 +574,10 @@ def host_capacity(cores, min_s=2.0, max_reads=24000):
             out["cli_8gpu_workers"] = good[len(good) // 2]
             out["cli_8gpu_workers_detail"] = {"reads": n, "runs": [r.get("rate", r.get("error")) for r in runs],
                                               "seconds": [r.get("seconds") for r in runs], "worker_processes": world,
-                                              "parser_threads_per_worker": runs[0].get("threads")}
+                                              "parser_threads_per_worker": runs[0].get("threads"),
+                                              "placement": runs[0].get("placement"),
+                                              "placement_rule": "cli.worker_cpus(rank, 8, devices 0..7): GPU r's NUMA node where the box has "
+                                                                "that GPU, contiguous slices of the allowed cores otherwise"}
         else:
             out["cli_8gpu_workers"] = {"error": runs[0].get("error")}
         if base is not None:
@@ -722,6 +729,11 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_h
     if cli_helper is not None:                               # the command line itself, in a process of its own
         cores, _, _ = host_cores()
         hi["cli_e2e"] = cli_helper.ask({"cmd": "cli", "reps": args.cli_reps, "threads": min(cores, 16), "gpus": 1})
+        # BASELINE.json configs[2] through the command line: human weights, 10 000 fast5 files in, 10 000 FASTA files out,
+        # built from ALL FIVE of the reference's fixture reads, every file a copy of its own (tmpfs)
+        if args.cli_human_reps > 0:
+            hi["cli_e2e_human"] = cli_helper.ask({"cmd": "cli", "reps": args.cli_human_reps, "threads": min(cores, 16), "gpus": 1,
+                                                  "species": "human", "all_five": True, "copy": True})
 
     # ---- C5: one long read, human weights, streamed in device-formed window groups
     h1, h2 = load_species("human")
@@ -757,7 +769,9 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_h
     fev = np.concatenate([r.feat_ev for r in reads])
     nb = sum(len(r.feat_ev) for r in reads)
     cfg = {}
-    for name, sp, batch, reps in (("C2", "ecoli", 512, 10), ("C3", "human", 4096, 40)):
+    # BASELINE.json configs[1] "~1k reads, batch=512" and configs[2] "human model, ~10k reads, batch=4096": 200 / 2000 passes
+    # over the five fixture reads (one pass = one call = 5 reads; the same read is revised again, results are not cached)
+    for name, sp, batch, reps in (("C2", "ecoli", 512, args.c2_reps), ("C3", "human", 4096, args.c3_reps)):
         a, b = load_species(sp)
         rv = Reviser(a, b, device=local_rank, batch=batch, precision=args.precision)
         rv.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -771,6 +785,8 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_h
         dth = _time_calls(lambda: rv.predict_reads_raw(*raws), lambda: None, max(2, reps // 4))
         cfg[name] = {"config": f"{sp} weights, T={a.T}, batch={batch} windows per launch group, the five fixture reads "
                                f"({nb} bases) x {reps} = {5 * reps} reads; fast5 parsing excluded",
+                     "reads": 5 * reps, "bases": n * reps, "seconds_device_resident": dt * reps,
+                     "reads_host_inclusive": 5 * max(2, reps // 4),
                      "bases_per_s_device_resident": n / dt,
                      "bases_per_s_host_inclusive_raw_reads": n / dth,
                      "achieved_tflops": n * FLOP_PER_BASE_DEDUP[11] / dt / 1e12}
@@ -821,6 +837,14 @@ def measure(rv, step, sync, d, args, prime, rank0):
         rv.prof_read()
     elapsed, mine = timed_steps(d, step, sync, args.steps, 0)
     prof = rv.prof_read() if prof_mode else {}
+    # the spread of THIS run: the same K-step block four more times (barrier + sync around each, max over ranks), so that a
+    # reader can tell box-to-box variance (+-4-8 % between boxes) from change; `value` stays the first block's (the contract)
+    blocks = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, getattr(args, "blocks", 5) - 1)):
+        e2, _ = timed_steps(d, step, sync, args.steps, 0)
+        blocks.append(e2 / args.steps * 1e3)
+    if prof_mode:
+        rv.prof_read()                                   # drop the extra blocks' samples: roofline = the contract block's
     kernel_us = {}
     if prof_mode and rank0:
         rv.prof_enable(1)
@@ -834,11 +858,29 @@ def measure(rv, step, sync, d, args, prime, rank0):
     overhead_us = rv.prof_overhead_us() if prof_mode and rank0 else 0.0
     return {"elapsed": elapsed, "mine": mine, "ms_per_step": elapsed / args.steps * 1e3, "prof": prof,
             "kernel_us": kernel_us, "prof_mode": prof_mode, "bracket_overhead_us": overhead_us,
-            "settle_ms": [round(x, 4) for x in settle]}
+            "settle_ms": [round(x, 4) for x in settle], "blocks_ms": blocks}
 
 
 KERNEL_NAME = {"bf16x3": "lstm_split_kernel<32,16,128,2,1>", "f32": "lstm_layer_kernel<32,16,128,1,1>",
                "f16x2": "lstm_h2w_kernel<32,16,128> (16x16x32 f16 tiles, eight waves in two groups)"}
+
+
+def rocprof_duration_us(precision, profiles_dir=None):
+    """Average duration of the dominant kernel in the newest COMMITTED rocprofv3 kernel trace of the timed region
+    (profiles/r*_kernel_stats_timed_region_<precision>.csv, written by scripts/gpu_prof.sh from this very command) ->
+    (microseconds, file name) or (None, reason).  The line's own hipEvent figure and the committed trace then sit side by
+    side in `roofline` (frac / frac_rocprof) and cannot drift apart unseen (VERDICT r05 next #4)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), f"r*_kernel_stats_timed_region_{precision}.csv")))
+    for path in reversed(files):
+        try:
+            for row in csv.DictReader(open(path)):
+                if KERNEL_SIGNATURE[precision] in row.get("Name", ""):
+                    return float(row["AverageNs"]) / 1e3, os.path.basename(path)
+        except Exception:
+            continue
+    return None, "no committed kernel trace names " + KERNEL_SIGNATURE[precision]
 
 
 def roofline_blocks(args, T, B, precision, m, suffix=""):
@@ -876,6 +918,9 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
         "executed_tflops": ach * PRODUCTS[precision],
         "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
     }
+    rp_us, rp_src = rocprof_duration_us(precision)
+    out["roofline" + suffix].update({"frac_rocprof": (fl / (rp_us * 1e-6) / 1e12 / peak) if rp_us else None,
+                                     "avg_launch_us_rocprof": rp_us, "rocprof_source": rp_src})
     # north_star: "rocprof HBM GB/s and MFMA utilisation reported against gfx950 peak" - from the committed PMC pass of this
     # kernel (null, with the reason in traffic_source, when that pass no longer describes the kernel)
     tr, _, rec = load_traffic(T, B, precision)
@@ -893,11 +938,12 @@ def roofline_blocks(args, T, B, precision, m, suffix=""):
         r["traffic_step_note"] = (f"HBM-side bytes of all launches of one {B}-window step (PMC, FETCH_SIZE x2 + WRITE_SIZE) against "
                                   f"{B * (T * 56 * 4 + 11 * 4 + 2)} algorithmic bytes in / out")
     if precision == "f16x2":
-        # measured, not assumed (profiles/r04_clock_vs_fill.txt, profiles/r04_power_by_launch.json)
-        out["roofline" + suffix]["power_note"] = (
-            "this launch runs at the socket's 1400 W cap with the shader clock pulled down to ~1.85 GHz; the layers' inner loop "
-            "alone (weights from L2, fragments from LDS, chains of v_mfma_f32_16x16x32_f16 on every SIMD, random operands) "
-            "sustains 421-455 TFLOP/s f32-grade = 0.51-0.55 of `peak` whatever the fill of the matrix pipe")
+        # measured, not assumed (profiles/r06_clock_vs_fill.txt)
+        out["roofline" + suffix]["bound_note"] = (
+            "what binds this launch is its weight stream, not the matrix pipe and not a power plateau (r06: the layers' inner loop "
+            "alone, every wave stamped): 2 KB of weights from L2 per wave and 12 products = ~30 B per cycle and CU, the rate the L2 "
+            "delivers to a CU; it holds the pipe's fill at 0.70 and costs clock (1.89 GHz on random operands); the same loop "
+            "without the stream fills the pipe to 0.94 at 1.82-1.86 GHz = 600-611 TFLOP/s f32-grade (0.72-0.73 of `peak`)")
     whole = flop_per_window(T) * B / (m["ms_per_step"] * 1e-3) / 1e12
     out["roofline_whole_step" + suffix] = {"achieved": whole, "peak": peak, "unit": "TFLOP/s", "frac": whole / peak,
                                            "frac_of_f32_mfma_peak": whole / PEAK_F32_MFMA_TFLOPS,
@@ -923,7 +969,7 @@ class Helper:
         self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--helper"],
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
 
-    def ask(self, cmd, timeout=900):
+    def ask(self, cmd, timeout=2400):       # >= the sum of the child timeouts of one command (cli_e2e: 2 x 800 s)
         import threading
         box = {}
 
@@ -945,7 +991,11 @@ class Helper:
         t.start()
         t.join(timeout)
         if t.is_alive():
-            self.p.kill()
+            self.p.terminate()                               # SIGTERM: helper_main's handler ends the command line it started
+            try:
+                self.p.wait(10)
+            except Exception:
+                self.p.kill()
             return {"error": f"helper did not answer {cmd.get('cmd')} within {timeout} s"}
         return box.get("r", {"error": "no answer"})
 
@@ -957,8 +1007,42 @@ class Helper:
                 self.p.kill()
 
 
+_CHILDREN = []          # process groups the helper has started (the command line and its GPU workers)
+
+
+def _run_child(cmd, timeout, env):
+    """subprocess.run in a process group of its own, remembered so that a helper that is told to stop (or times out)
+    takes the command line AND its GPU workers with it (a killed helper left the grandchild on the GPUs)."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    _CHILDREN.append(p)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        out, err = p.communicate()
+        err = (err or "") + f"\n[bench] timed out after {timeout} s"
+        p.returncode = p.returncode if p.returncode else -9
+    finally:
+        _CHILDREN.remove(p)
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 def helper_main():
     """Body of the helper child (no GPU call in this process, ever)."""
+    import signal
+
+    def stop(signum, frame):
+        for p in list(_CHILDREN):
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+        os._exit(1)
+    signal.signal(signal.SIGTERM, stop)
     for line in sys.stdin:
         try:
             cmd = json.loads(line)
@@ -968,7 +1052,9 @@ def helper_main():
             break
         try:
             if cmd.get("cmd") == "cli":
-                res = cli_e2e(cmd.get("reps", 4000), cmd.get("threads", 16), cmd.get("gpus", 1), cmd.get("share", False))
+                res = cli_e2e(cmd.get("reps", 4000), cmd.get("threads", 16), cmd.get("gpus", 1), cmd.get("share", False),
+                              species=cmd.get("species", "ecoli"), all_five=bool(cmd.get("all_five", False)),
+                              copy=bool(cmd.get("copy", False)))
             elif cmd.get("cmd") == "hostcap":
                 res = host_capacity(int(cmd.get("cores", 1)), float(cmd.get("min_s", 2.0)))
             else:
@@ -979,13 +1065,19 @@ def helper_main():
     return 0
 
 
-def cli_e2e(reps, threads, gpus=1, share=False):
-    """`python NanoReviser.py --gpus N` on the committed fixture reads x reps x N (weak scaling: the file set grows with
-    the GPUs), as a child process of the helper, wall time from outside, start-up included."""
+def cli_e2e(reps, threads, gpus=1, share=False, species="ecoli", all_five=False, copy=False):
+    """`python NanoReviser.py --gpus N -S <species>` on the committed fixture reads x reps x N (weak scaling: the file set
+    grows with the GPUs), as a child process of the helper, wall time from outside, start-up included.
+    all_five: the reference's five fixture reads (tests/golden/fast5 + fast5_more) instead of the first two.
+    copy: every input file is a COPY - its own inode, its own pages - instead of a symbolic link to one of the fixtures
+    (two hot files read 4000 times each sit in the CPU caches; 10 000 distinct files do not);
+    falls back to links, and says so, when the scratch filesystem has no room for reps x the fixtures' bytes."""
     import glob
     import shutil
     import tempfile
     src = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fast5", "*.fast5")))
+    if all_five:
+        src = sorted(src + glob.glob(os.path.join(ROOT, "tests", "golden", "fast5_more", "*.fast5")))
     base, base_what = scratch_base()
     work = tempfile.mkdtemp(prefix="nrv_cli_e2e_", dir=base)
     env = dict(os.environ)
@@ -996,10 +1088,26 @@ def cli_e2e(reps, threads, gpus=1, share=False):
     try:
         din, dout = os.path.join(work, "in"), os.path.join(work, "out") + "/"
         os.makedirs(din)
+        need = sum(os.path.getsize(f) for f in src) * reps * gpus
+        how = "symbolic links"
+        if copy:
+            free = shutil.disk_usage(work).free
+            try:
+                avail = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) * 1024
+            except Exception:
+                avail = free
+            # on tmpfs the copies are memory: leave two thirds of what is free / available alone
+            how = "copies (one inode and one set of pages per read)" if 3 * need < min(free, avail) else \
+                f"symbolic links (no room for {need >> 20} MiB of copies: {min(free, avail) >> 20} MiB free)"
         for i, f in enumerate(src):
             for k in range(reps * gpus):
-                os.symlink(f, os.path.join(din, f"r{i}_{k}.fast5"))
-        res = {"reads": len(src) * reps * gpus, "threads": threads, "n_gpus": gpus, "share_device": bool(share), "files_on": base_what}
+                dst = os.path.join(din, f"r{i}_{k}.fast5")
+                if how.startswith("copies"):
+                    shutil.copyfile(f, dst)
+                else:
+                    os.symlink(f, dst)
+        res = {"reads": len(src) * reps * gpus, "threads": threads, "n_gpus": gpus, "share_device": bool(share), "files_on": base_what,
+               "species": species, "distinct_fixture_reads": len(src), "input_files_are": how, "input_bytes": need}
         for name, n in (("start_up", 2), ("run", None)):     # two reads first: what a run costs before it streams
             if n is not None:
                 d2 = os.path.join(work, "in2")
@@ -1008,9 +1116,9 @@ def cli_e2e(reps, threads, gpus=1, share=False):
                     if not os.path.exists(os.path.join(d2, f)):
                         os.symlink(os.path.realpath(os.path.join(din, f)), os.path.join(d2, f))
             t0 = time.perf_counter()
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "NanoReviser.py"), "-d", din if n is None else d2,
-                                "-o", dout, "-S", "ecoli", "--thread", str(threads), "--gpus", str(gpus if n is None else 1)],
-                               capture_output=True, text=True, timeout=800, env=env)
+            r = _run_child([sys.executable, os.path.join(ROOT, "NanoReviser.py"), "-d", din if n is None else d2,
+                            "-o", dout, "-S", species, "--thread", str(threads), "--gpus", str(gpus if n is None else 1)],
+                           800, env)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 res["error"] = f"{name}: rc {r.returncode}: {r.stderr[-300:]}"
@@ -1023,7 +1131,7 @@ def cli_e2e(reps, threads, gpus=1, share=False):
                 res.update({"wall_s": dt, "bases": nb, "bases_per_s": nb / dt,
                             "files_written": len([f for f in os.listdir(dout) if f.endswith("_out.fasta")]),
                             "cli_report": line[-1].strip() if line else None})
-        res["what"] = (f"python NanoReviser.py -d <{len(src)} committed fixture fast5 x {reps * gpus}, symlinked> -o <tmp> -S ecoli "
+        res["what"] = (f"python NanoReviser.py -d <{len(src)} committed fixture fast5 x {reps * gpus}, {how.split(' (')[0]}> -o <tmp> -S {species} "
                        f"--thread {threads} --gpus {gpus}: own HDF5 reader, event collapse, device-side segmentation, "
                        "model1+model2, merge, one FASTA per read; wall time of the child process, start-up included"
                        + ("; NRV_SHARE_DEVICE=1: the workers share the devices there are (rehearsal)" if share else ""))
@@ -1095,6 +1203,15 @@ def run_rank(args):
              "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
              "uuid": str(getattr(pr, "uuid", ""))}
     devices = d.gather_obj(ident)
+    n_distinct = len({(x["pci"], x["uuid"]) for x in devices})
+    if n_distinct < d.world and not args.share_device:
+        # an N-GPU line that ran on fewer than N devices is not an N-GPU measurement (the data path has no collective that
+        # would notice): refuse, loudly, before anything is timed (every rank sees the same gathered list and leaves)
+        if d.rank == 0:
+            print(f"bench.py: {d.world} ranks but only {n_distinct} distinct device(s) {[x['pci'] for x in devices]}; "
+                  "--share-device maps ranks onto the devices there are (a rehearsal, never a scaling figure)", file=sys.stderr, flush=True)
+        d.close()
+        sys.exit(3)
 
     T, B = args.window, args.batch
     m1, m2 = load_species(args.species)
@@ -1132,6 +1249,11 @@ def run_rank(args):
     value = total / elapsed
     rank_ms = m["mine"] / args.steps * 1e3
     rank_ms_min, rank_ms_max = d.min_float(rank_ms), d.max_float(rank_ms)
+    per_rank = d.gather_obj({"rank": d.rank, "ms_per_step": rank_ms})                # every rank's own clock, next to its device
+    if per_rank and devices:
+        by_rank = {x["rank"]: x["ms_per_step"] for x in per_rank}
+        for x in devices:
+            x["ms_per_step"] = by_rank.get(x["rank"])
     # the f16x2 range guard must not have fired on the benchmark's own input (a re-run would not be in `value`)
     pending, _ = rv.saturated()
     if d.sum_int(pending) != 0:
@@ -1142,8 +1264,14 @@ def run_rank(args):
         "n_gpus": args.gpus, "world_size": d.world, "steps": args.steps, "warmup": args.warmup,
         "prime": args.prime,
         "ms_per_step": ms_per_step,
+        "ms_per_step_blocks": [round(x, 5) for x in m["blocks_ms"]],
+        "ms_per_step_blocks_min_median_max": [round(x, 5) for x in (min(m["blocks_ms"]), sorted(m["blocks_ms"])[len(m["blocks_ms"]) // 2],
+                                                                   max(m["blocks_ms"]))],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE[args.precision],
+        "value_arithmetic": ("`value` is computed on " + DTYPE[args.precision] + "; the figure on the reference's own IEEE-f32 "
+                             "arithmetic, same protocol, same run: value_reference / dtype_reference / roofline_reference")
+                            if args.precision != "f32" else "`value` is computed on IEEE-f32 matrix instructions, the reference's precision",
         "data": "synthetic",
         "config": {
             "workload": f"{args.species} weights, synthetic independent {T}-event windows (SURVEY 8d C4 "
@@ -1179,6 +1307,15 @@ def run_rank(args):
                 out["value_f32"] = out["roofline_f32"]["bases_per_s"]
                 out["ms_per_step_f32"] = out["roofline_f32"]["ms_per_step"]
                 out["dtype_f32"] = DTYPE["f32"]
+                # ... and under the names a reader looks for first
+                out["dtype_reference"] = "f32"
+                out["value_reference"] = out["roofline_f32"]["bases_per_s"]
+                out["ms_per_step_reference"] = out["roofline_f32"]["ms_per_step"]
+                out["roofline_reference"] = {k: out["roofline_f32"].get(k) for k in
+                                             ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "avg_launch_us",
+                                              "avg_launch_us_rocprof", "rocprof_source", "traffic")}
+            if "cli_e2e_human" in out.get("host_inclusive", {}):
+                out["cli_e2e_human"] = out["host_inclusive"]["cli_e2e_human"]
         except Exception as e:                               # never lose the main line to a secondary block
             out["extras_error"] = repr(e)
     if args.gpus > 1 and not args.no_extras and not args.no_cli_e2e:
@@ -1231,6 +1368,11 @@ def main(argv=None):
     ap.add_argument("--no-cli-e2e", action="store_true", help="skip host_inclusive.cli_e2e (the CLI in a child process)")
     ap.add_argument("--cli-reps", type=int, default=4000, help="cli_e2e: copies of each committed fixture read (x N with --gpus N)")
     ap.add_argument("--hostcap-seconds", type=float, default=2.0, help="cpu_baseline.host_capacity: seconds per point")
+    ap.add_argument("--blocks", type=int, default=5, help="timed K-step blocks (the first is `value`; all are in ms_per_step_blocks)")
+    ap.add_argument("--c2-reps", type=int, default=200, help="configs.C2: passes over the five fixture reads (200 = 1000 reads)")
+    ap.add_argument("--c3-reps", type=int, default=2000, help="configs.C3: passes over the five fixture reads (2000 = 10 000 reads)")
+    ap.add_argument("--cli-human-reps", type=int, default=2000,
+                    help="cli_e2e_human: copies of each of the five fixture reads (2000 = 10 000 files, ~8.8 GB on tmpfs; 0 = skip)")
     ap.add_argument("--helper", action="store_true", help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)

@@ -20,8 +20,10 @@ Changed on purpose:
     (--gpus, default all); --thread bounds the host-stage worker processes per GPU worker;
   * explicitly given --model{1,2}_predict_dir win over -S (in the reference -S always overrides
     them, which makes those flags dead, :191-193);
-  * --resume: a rerun skips the reads whose output file exists (the reference removes the output
-    directory and starts over, :196-201; SURVEY.md 5 "skip-if-exists is a free resume");
+  * --resume: a rerun skips the reads whose output file exists, EXCEPT those the earlier run listed in its
+    failed-reads file (their output is the unrevised fallback: they are revised again and replaced; the
+    reference clears temp_dir and re-revises / overwrites every read, :196-201; SURVEY.md 5
+    "skip-if-exists is a free resume"); --resume_keep_failed leaves those files alone and returns 3;
   * each GPU worker is pinned to the cores of its GPU's NUMA node (`worker_cpus`), and a very long
     read (BASELINE config 5) is split over the GPU workers by window range with a T-1-event halo
     (`shard.split_read_windows`, `plan_splits`): still no device-to-device exchange.
@@ -76,7 +78,12 @@ def get_args(argv: Optional[Sequence[str]] = None):
     p.add_argument("--model_dir", default=None, help="root of model/<species>/ (default: next to the package)")
     p.add_argument("--resume", action="store_true", default=False,
                    help="skip every read whose <stem>_out.<format> already exists and is not empty (outputs are written "
-                        "through a temporary + rename, so an existing file is a finished one)")
+                        "through a temporary + rename, so an existing file is a complete one) - except the reads the earlier "
+                        "run listed in its failed-reads file: their output holds the ORIGINAL basecalls (a GPU worker died, "
+                        "the engine failed), so they are revised again and the file is replaced")
+    p.add_argument("--resume_keep_failed", action="store_true", default=False,
+                   help="with --resume: do not redo the reads of the failed-reads file either; they stay listed there and "
+                        "the exit code is 3 while any of them is left")
     p.add_argument("--split_reads_above", type=float, default=float(os.environ.get("NRV_SPLIT_READS_MB", "4")),
                    help="with more than one GPU: a fast5 file above this many MB (~10 MB per 100 k events) AND above a GPU "
                         "worker's fair share of the input has its window range split over the workers, T-1 events of halo "
@@ -897,6 +904,48 @@ def worker_cpus(rank: int, world: int, devices: Optional[Sequence[int]] = None, 
     return part if len(part) >= 2 else None
 
 
+def probe_rename_rate(out_dir: str, pairs: int = 2000) -> Optional[float]:
+    """create + write + rename pairs per second the OUTPUT directory's filesystem sustains (one output per read appears
+    that way: write_read / nrvh_finish_read), measured on `pairs` small files in a scratch sub-directory.  Why: r05 found
+    the sandbox's overlay root to cost ten times the system time of a real filesystem once a directory has seen a few
+    thousand creates + renames - the same eight workers fed 68-78 M bases/s writing there and 120-131 M writing to tmpfs,
+    i.e. less than eight GPUs consume.  None when the directory cannot be probed."""
+    d = os.path.join(out_dir, f".nrv_probe_{os.getpid()}")
+    try:
+        os.makedirs(d, exist_ok=True)
+        payload = b">probe\n" + b"ACGT" * 2048                 # ~8 KB: a typical record
+        t0 = time.perf_counter()
+        for i in range(pairs):
+            tmp = os.path.join(d, f"p{i}.tmp")
+            with open(tmp, "wb") as fp:
+                fp.write(payload)
+            os.replace(tmp, os.path.join(d, f"p{i}_out.fasta"))
+        dt = time.perf_counter() - t0
+        return pairs / max(dt, 1e-9)
+    except OSError:
+        return None
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def check_output_rate(args, world: int, n_reads: int, log=print) -> Optional[float]:
+    """With several GPU workers and enough reads for it to matter: warn when the output directory cannot take the files the
+    GPUs will produce.  One MI355X revises ~12.5 M bases/s = ~1600 reads of 8 k bases per second; ONE thread's probe rate
+    must cover the whole run's share with a factor of two to spare (the finishers are a few threads per worker).
+    NRV_OUTPUT_PROBE=0 turns the probe off, =1 forces it."""
+    mode = os.environ.get("NRV_OUTPUT_PROBE", "")
+    if mode == "0" or (mode != "1" and (world < 2 or n_reads < 4000)):
+        return None
+    rate = probe_rename_rate(args.output_dir)
+    need = 1600.0 * world
+    if rate is not None and rate < 2.0 * need:
+        log(f"[！！！Warning] the output directory sustains {rate:.0f} file creations + renames per second (one thread, "
+            f"2000 files); {world} GPU workers produce up to ~{need:.0f} reads per second.  The run will be bound by this "
+            "filesystem, not by the GPUs: put -o on a local disk or a tmpfs (overlay / network filesystems are the usual cause).")
+    return rate
+
+
 def share_device() -> bool:
     """NRV_SHARE_DEVICE=1: worker rank r drives device r % device_count - a 1-GPU box rehearsing the N-worker command
     line with the real engine (bench.py --share-device, tests/test_gpu_multirank.py).  Never the default."""
@@ -1115,7 +1164,9 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
     kept_failed, n_resumed = [], 0
     if args.resume:
         # A finished read is a non-empty <stem>_out.<fmt>: outputs only ever appear by rename of a complete temporary.
-        # Reads an earlier run wrote UNREVISED stay in the failed-reads file (their output exists, so they are skipped).
+        # Reads an earlier run wrote UNREVISED (fallback after a lost GPU worker / an engine failure / a failed split-read
+        # merge) are in its failed-reads file: they are taken out of `skip` and revised again - write_read replaces the
+        # output atomically.  --resume_keep_failed: they stay as they are, stay listed, and the run returns 3.
         def done(f):
             try:
                 return os.path.getsize(out_name(args.output_dir, f, args.output_format)) > 0
@@ -1124,11 +1175,19 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         skip = {f for f in names if done(f)}
         try:
             with open(os.path.join(args.output_dir, args.failed_reads_filename)) as fp:
-                kept_failed = [ln.strip() for ln in fp if ln.strip() in skip]
+                earlier_failed = [ln.strip() for ln in fp if ln.strip() in skip]
         except OSError:
-            pass
+            earlier_failed = []
+        if args.resume_keep_failed:
+            kept_failed = earlier_failed
+            if kept_failed:
+                rc = 3
+        else:
+            skip -= set(earlier_failed)
         n_resumed, names = len(skip), [f for f in names if f not in skip]
-        print(f"[s:::] --resume: {n_resumed} reads already have their output, {len(names)} to do")
+        print(f"[s:::] --resume: {n_resumed} reads already have their output, {len(names)} to do"
+              + (f" ({len(earlier_failed)} of them written unrevised by the earlier run"
+                 + (", left as they are)" if args.resume_keep_failed else ", revised again)") if earlier_failed else ""))
     if reviser_factory is not None:       # in-process (tests / embedding): one engine, no sharding
         rv = reviser_factory(args, 0)
         stats = [process_files(args, names, rv, print)]
@@ -1152,6 +1211,7 @@ def main(argv: Optional[Sequence[str]] = None, reviser_factory=None, standalone:
         units, usz = plan_splits(names, sizes, want, args.split_reads_above)
         world = max(1, min(want, len(units)))
         parts = shard_reads(usz, world)
+        check_output_rate(args, world, len(names), lambda m: print(m, file=sys.stderr))
         if world == 1:
             made = []
 

@@ -72,9 +72,6 @@ static bool make_blob(const nrv_weights* w, int T, int C, Blob* b) {
 // HOST optimiser, which would fully unroll the constant-bound packing loops below (an 11-minute
 // host compile).  Every loop of the packing code therefore carries an explicit "do not unroll" - the code
 // is still optimised otherwise (round 2 had the optimiser off altogether: 0.12 s of packing per nrv_create).
-#ifndef NRV_FRONT
-#define NRV_FRONT 0
-#endif
 #define NRV_HOST_COLD __attribute__((noinline))
 #define NRV_FOR _Pragma("clang loop unroll(disable)") for
 // One packed k-group for one 32-column tile: dst[lane][j] = get(k = 8*kg + 4*(lane>>5) + j, lane&31)
@@ -230,7 +227,7 @@ NRV_HOST_COLD static void pack_lstm_h2s(const Blob& b, int base, int K0, int s0,
   memcpy(out.data(), w.data(), w.size() * 2);
 }
 
-// lstm2_t_kernel (nrv_lstm2_t.h): the 32->64 layer's weights as A operands of the transposed product.
+// lstm2_u_kernel (nrv_lstm2_u.h): the 32->64 layer's weights as A operands of the transposed product.
 // [dir][kb 3: input, recurrent 0, recurrent 1][tile mt 16][term 2][64 lanes][8 f16]; tile mt = gate g * 4 + unit tile ut;
 // lane l = (m = l & 15, q = l >> 4) holds gate-unit (g, u = 16 ut + m) for the k slots 8 q + j:
 //   input block      feature 8 q + j                                   x 2^(E - s_in)
@@ -463,15 +460,14 @@ struct DevModel {
   // shift with the buffer exponents folded in, the producers' scaled epilogue constants
   size_t l_s2[4], l_h2[4];
   // layers 2, 3 (192->128, 256->64) with the BatchNorm IN FRONT of them folded into their weights and bias:
-  // their BatchNorm'd input segment is then the raw h x 2^13 of the layer before (lstm2_t / lstm_h2s RAW copy-out)
+  // their BatchNorm'd input segment is then the raw h x 2^13 of the layer before (lstm2_u / lstm_h2s RAW copy-out)
   size_t l_w2sf[4] = {0, 0, 0, 0}, l_b2sf[4] = {0, 0, 0, 0};
   float descale_f[4] = {1.f, 1.f, 1.f, 1.f};
-  size_t l2t_w = 0, l2t_b = 0;      // lstm2_t_kernel: transposed fragments / bias image of the 32->64 layer
+  size_t l2t_w = 0, l2t_b = 0;      // lstm2_u_kernel: transposed fragments / bias image of the 32->64 layer
   float descale[4];
   size_t l1s2, l1h2;
   size_t cr_dbias = 0;                   // cnn_r_kernel: dense bias x 2^16
   size_t cr_w2 = 0, cr_ep = 0, cr_d = 0; // cnn_r_kernel: conv2 in its two-position form, epilogue constants, dense A fragments
-  size_t cr_c1 = 0;                      // cnn_r_kernel: conv1 as a matrix product: per-lane A operand, bias, BatchNorm 1
   size_t fw8 = 0;                        // head_h2_kernel: feature kernel as its LDS image [16][T][8]
   CnnRConsts cr_k;                       // ... and the first convolution's constants (kernel arguments)
   size_t h_w2, h_b2;          // head_h2_kernel: f16x2 weights, scaled biases
@@ -509,8 +505,8 @@ struct nrv_handle {
   static constexpr int kIn = 3;
   float *d_sig[kIn] = {0, 0, 0}, *d_feat[kIn] = {0, 0, 0}, *d_p[2][2] = {{0, 0}, {0, 0}};
   int8_t* d_a[2][2] = {{0, 0}, {0, 0}};
-  // ONE device block per staging set, laid out as its page-locked mirror pin_out: [p1 rows x 6 f32 | p2 rows x 5 f32 | a1 rows |
-  // a2 rows | range-guard counter]: a stage's results come back in ONE copy (r05: six copies of ~13 us each stood between a
+  // ONE device block per staging set, laid out as its page-locked mirror pin_out: [range-guard counter, 64 B | p1 r x 6 f32 |
+  // p2 r x 5 f32 | a1 r | a2 r], r = the stage's rows padded to kRowPad: a stage's results come back in ONE copy of its own size (r05: six copies of ~13 us each stood between a
   // stage's last kernel and the host's hand-over, and the next upload, enqueued behind that, ended after the running stage did)
   char* d_out[2] = {0, 0};
   unsigned* d_sat_st[2] = {nullptr, nullptr};
@@ -534,6 +530,8 @@ struct nrv_handle {
   unsigned* d_sat = nullptr;
   unsigned* pin_sat[2] = {nullptr, nullptr};
   unsigned sat_seen[2] = {0, 0};   // the staging sets' counters only grow: a stage fired iff its counter moved since the last look
+  bool host_call_open = false;     // a host-pointer call that left through an error path: its stages may have moved the counters
+                                   // without anybody looking - the next call reads them back first
   int64_t sat_reruns = 0;          // pipeline stages the host entry points re-ran on the f32 kernels
   int h2 = 1;                      // 1: f16x2 mode (the default) - lstm2..4 on lstm_h2o / lstm_h2s_kernel, activations between the kernels
                                    // as f16 split planes (cnn dense and head stay on their bf16x3 kernels)
@@ -561,11 +559,9 @@ namespace {
     }                                                                                    \
   } while (0)
 
-// 192 -> 128 layer: NRV_L3_WS = 1: lstm_h2w_kernel (eight waves, one unit group of 16 each, nrv_lstm_f16x2w.h); 0: lstm_h2s_kernel
-#ifndef NRV_L3_WS
-#define NRV_L3_WS 1
-#endif
-static const int kUhS[4] = {0, 1, NRV_L3_WS ? 1 : 2, 1};      // unit halves per wave of the f16x2 kernels of lstm2..4
+// unit halves (16 units each) per wave of the f16x2 kernels of lstm2..4: lstm_h2w_kernel (192 -> 128) and lstm_h2s_kernel (256 -> 64)
+// both give a wave one unit group of 16
+static const int kUhS[4] = {0, 1, 1, 1};
 
 NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int C) {
   const int T = h->T;
@@ -701,23 +697,6 @@ NRV_HOST_COLD static int upload_model(nrv_handle* h, int mi, const Blob& b, int 
         d.cr_d = put(d2.data(), d2.size());
       }
       const float* c0 = host.data() + d.conv;                  // unscaled: w1 24, b1 8, s1 8, h1 8
-      {
-        // conv1 as v_mfma_f32_16x16x4_f32 (nrv_cnn_r.h, NRV_CNNR_C1MFMA): A[m][k] for lane (m = l & 15, k = l >> 4): rows 0-7
-        // channel m of position P (taps k = 0..2), rows 8-15 channel m - 8 of position P + 1 (taps k - 1); the result lane
-        // (n, q) holds rows 4 q .. + 3: channels (4 q + r) & 7 - its bias, BatchNorm 1 scale / shift x 2^6
-        float tab[64 * 16] = {0};
-        NRV_FOR (int lane = 0; lane < 64; ++lane) {
-          const int m = lane & 15, k = lane >> 4, co = m & 7, tap = m < 8 ? k : k - 1;
-          tab[lane * 16] = (tap >= 0 && tap < 3) ? c0[tap * 8 + co] : 0.f;
-          NRV_FOR (int r = 0; r < 4; ++r) {
-            const int ch = (4 * k + r) & 7;
-            tab[lane * 16 + 4 + r] = c0[24 + ch];
-            tab[lane * 16 + 8 + r] = std::ldexp(c0[32 + ch], 6);
-            tab[lane * 16 + 12 + r] = std::ldexp(c0[40 + ch], 6);
-          }
-        }
-        d.cr_c1 = put(tab, 64 * 16);
-      }
       memcpy(d.cr_k.w1, c0, 24 * 4);
       memcpy(d.cr_k.b1, c0 + 24, 8 * 4);
       NRV_FOR (int o = 0; o < 8; ++o) { d.cr_k.s1[o] = std::ldexp(c0[32 + o], 6); d.cr_k.h1[o] = std::ldexp(c0[40 + o], 6); }
@@ -896,12 +875,15 @@ static int ensure_workspace(nrv_handle* h) {
     HIPCHK(h, hipMemset(h->d_out[st], 0, ob + 64));
     HIPCHK(h, hipHostMalloc((void**)&h->pin_out[st], ob + 64, hipHostMallocDefault));
     memset(h->pin_out[st], 0, ob + 64);
-    h->d_p[st][0] = (float*)h->d_out[st];
-    h->d_p[st][1] = (float*)(h->d_out[st] + (size_t)rows * 24);
-    h->d_a[st][0] = (int8_t*)(h->d_out[st] + (size_t)rows * 44);
-    h->d_a[st][1] = (int8_t*)(h->d_out[st] + (size_t)rows * 45);
-    h->d_sat_st[st] = (unsigned*)(h->d_out[st] + ob);
-    h->pin_sat[st] = (unsigned*)(h->pin_out[st] + ob);
+    // [range-guard counter, 64 B][p1 r x 6 f32 | p2 r x 5 f32 | a1 r | a2 r], r = the STAGE's rows padded to kRowPad: the
+    // counter sits in front so that one copy of 64 + r x 46 bytes carries a short stage whole (a call of one short
+    // read downloaded the block of the largest stage); the defaults below are the full-size layout
+    h->d_p[st][0] = (float*)(h->d_out[st] + 64);
+    h->d_p[st][1] = (float*)(h->d_out[st] + 64 + (size_t)rows * 24);
+    h->d_a[st][0] = (int8_t*)(h->d_out[st] + 64 + (size_t)rows * 44);
+    h->d_a[st][1] = (int8_t*)(h->d_out[st] + 64 + (size_t)rows * 45);
+    h->d_sat_st[st] = (unsigned*)h->d_out[st];
+    h->pin_sat[st] = (unsigned*)h->pin_out[st];
     h->sat_seen[st] = 0;
   }
   h->cap_rows = rows;
@@ -1077,7 +1059,6 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
   };
   int rc;
 
-  bool h2_fused_l2 = false;          // ... and the 32 -> 64 Bi-LSTM too (NRV_FRONT)
   bool h2_fused_l1 = false;          // f16x2 mode: the 6 -> 16 Bi-LSTM ran inside the signal-branch launch
   // 0: signal branch.  (Running it on a second stream beside lstm1/lstm2 was measured: the
   // dispatcher serialises the two launches anyway - each fills the LDS/register file of every CU -
@@ -1091,7 +1072,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       CnnRArgs a2;
       for (int m = 0; m < 2; ++m) {
         const DevModel& d = h->dm[m];
-        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.cr_dbias, h->S[m], d.all + d.cr_c1};
+        a2.m[m] = CnnRModelParams{d.all + d.cr_w2, d.all + d.cr_ep, d.all + d.cr_d, d.all + d.cr_dbias, h->S[m]};
         a2.k[m] = d.cr_k;
       }
       a2.signal = d_sig; a2.T = Tc; a2.n_rows = n_rows; a2.n_tiles = n_tiles; a2.sat = sat;
@@ -1103,27 +1084,12 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                     read_mode ? 1 : 0, h->X1[m]};
       }
       // persistent, one workgroup of eight + four waves per CU and model; a conv wave takes 16-event units round-robin
-#if NRV_FRONT
-      // the whole front in one launch: four conv waves + four read-branch waves (6 -> 16 twice, then 32 -> 64)
-      for (int m = 0; m < 2; ++m) {
-        const DevModel& d = h->dm[m];
-        a2.l2[m] = Lstm2TModelParams{d.all + d.l2t_w, d.all + d.l2t_b, h->X1[m], h->X2[m], d.descale[1]};
-      }
-      {
-        const int wgc = (2 * n_tiles + kFrontConvWaves - 1) / kFrontConvWaves, wgr = 2 * ((n + 63) / 64);
-        int gx = wgc > wgr ? wgc : wgr;
-        gx = gx < 128 ? (gx + 1) & ~1 : 128;
-        if (h->act == 0) hipLaunchKernelGGL((cnn_r_kernel<0, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);
-        NRV_ACT1(else hipLaunchKernelGGL((cnn_r_kernel<1, true>), dim3(gx, 2), dim3(kFrontThreads), 0, h->stream, a2);)
-        h2_fused_l1 = h2_fused_l2 = true;
-      }
-#endif
       // workgroups per model: enough for the conv units (8 waves each) AND for the 6 -> 16 layer's units (4 waves each,
       // 2 units per 16 windows) - in read mode the signal branch runs per EVENT (n + T - 1 of them) but the 6 -> 16 layer
       // still per (window, step): sized by the conv units alone its 512 units queued on 33 workgroups
       const int wg_c = (2 * n_tiles + kCnnRWaves - 1) / kCnnRWaves, wg_l = (2 * ((n + 15) / 16) + kCnnRL1Waves - 1) / kCnnRL1Waves;
       const int wg = wg_c > wg_l ? wg_c : wg_l;
-      if (h2_fused_l2 || !NRV_RUN_STAGE(0)) {}
+      if (!NRV_RUN_STAGE(0)) {}
       else if (h->act == 0) hipLaunchKernelGGL(cnn_r_kernel<0>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);
       NRV_ACT1(else hipLaunchKernelGGL(cnn_r_kernel<1>, dim3(wg < 128 ? wg : 128, 2), dim3(kCnnRThreads), 0, h->stream, a2);)
       h2_fused_l1 = true;
@@ -1168,8 +1134,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
                                win_view(h->X1[m], 8), ActView{}, nullptr, 0, h->X2[m]};
     }
     const ActView none[2] = {ActView{}, ActView{}};
-    if (h2_fused_l2) {}
-    else if (h->h2) {
+    if (h->h2) {
       // wave-private transposed kernel; hands over h x 2^13 (BatchNorm(128) is in the 192->128 layer's weights)
       Lstm2TArgs ta;
       ta.T = T; ta.n_rows = n;
@@ -1179,13 +1144,8 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       }
       dim3 grid((n + 63) / 64, 2, 2);
       if (!NRV_RUN_STAGE(2)) {}
-#if NRV_L2_PAIR          // two waves per chain (nrv_lstm2_u.h, r05); 0: one wave per chain (nrv_lstm2_t.h) - bit-identical
       else if (h->act == 0) hipLaunchKernelGGL(lstm2_u_kernel<0>, grid, dim3(kL2uThreads), 0, h->stream, ta);
       NRV_ACT1(else hipLaunchKernelGGL(lstm2_u_kernel<1>, grid, dim3(kL2uThreads), 0, h->stream, ta);)
-#else
-      else if (h->act == 0) hipLaunchKernelGGL(lstm2_t_kernel<0>, grid, dim3(kL2tThreads), 0, h->stream, ta);
-      NRV_ACT1(else hipLaunchKernelGGL(lstm2_t_kernel<1>, grid, dim3(kL2tThreads), 0, h->stream, ta);)
-#endif
     }
     else if (h->split & 2) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[1], h->dm[1].all + h->dm[1].l_ws[1]};
@@ -1208,11 +1168,7 @@ static int run_group(nrv_handle* h, const float* d_sig, const float* d_feat, int
       // both big layers on lstm_h2s_kernel: this one hands over h x 2^13 as it lies in LDS and the BatchNorm
       // behind it lives in the next layer's weights
       // (cell state in registers; 1 of its 10 weight k-blocks of 32 resident in LDS: 64 KB)
-#if NRV_L3_WS
       if (NRV_RUN_STAGE(3)) launch_lstm_h2w<32, 16, 128>(h, 2, i0, i1, o, T, n, tiles);
-#else
-      launch_lstm_h2s<32, 16, 128, 2, 1, 2, 8, 2, 1, true>(h, 2, i0, i1, o, T, n, tiles);
-#endif
     } else if (h->split & 4) {
       const float* ws[2] = {h->dm[0].all + h->dm[0].l_ws[2], h->dm[1].all + h->dm[1].l_ws[2]};
       launch_lstm_split<32, 16, 128, 2, 1>(h, a, ws, tiles);
@@ -1625,6 +1581,12 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   const int64_t n = read_mode ? n_in - T : n_in;
   if (n <= 0) return NRV_OK;
   const size_t ev_all = read_mode ? (size_t)n_in : (size_t)n_in * T;
+  if (h->host_call_open) {                                 // the previous call failed somewhere in its pipeline
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int st = 0; st < 2; ++st)
+      if (h->d_sat_st[st]) HIPCHK(h, hipMemcpy(&h->sat_seen[st], h->d_sat_st[st], sizeof(unsigned), hipMemcpyDeviceToHost));
+  }
+  h->host_call_open = true;
   // NRV_HOST_TRACE=1: where a host-pointer call's wall time goes (registration, pipeline, drain, unregistration), to stderr
   static const bool trace = getenv("NRV_HOST_TRACE") && atoi(getenv("NRV_HOST_TRACE")) > 0;
   const auto t_0 = std::chrono::steady_clock::now();
@@ -1639,18 +1601,23 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   if (!raw_reads && !direct_s && (rc = grow_pinned(h, h->pin_sig, &h->pin_sig_cap, ev_grp * kSig * 4))) return rc;
   if (!direct_f && (rc = grow_pinned(h, h->pin_feat, &h->pin_feat_cap, ev_grp * kFeat * 4))) return rc;
 
-  // One stage's launch groups (on the lanes when they are small): inputs from staging set si, outputs to set st.
+  // One stage's launch groups (on the lanes when they are small): inputs from staging set si, outputs to set st, laid out
+  // for the stage's own row count (block_rows): counter | p1 | p2 | a1 | a2.
+  auto block_rows = [](int nb) -> size_t { return ((size_t)nb + kRowPad - 1) / kRowPad * kRowPad; };
   auto run_stage = [&](int nb, int si, int st) -> int {
+    const size_t r = block_rows(nb);
+    char* const d = h->d_out[st] + 64;
     return for_groups(h, nb, [&](int64_t w, int nw) {
       return run_group(h, h->d_sig[si] + (read_mode ? w * kSig : w * T * kSig),
                        h->d_feat[si] + (read_mode ? w * kFeat : w * T * kFeat), nw, read_mode,
-                       h->d_p[st][0] + w * 6, h->d_p[st][1] + w * 5, h->d_a[st][0] + w, h->d_a[st][1] + w, h->d_sat_st[st]);
+                       (float*)d + w * 6, (float*)(d + r * 24) + w * 5, (int8_t*)(d + r * 44) + w, (int8_t*)(d + r * 45) + w,
+                       h->d_sat_st[st]);
     });
   };
   auto finalize = [&](int64_t s, int nb, int si, int st) -> int {  // stage -> caller, one stage behind
     HIPCHK(h, hipEventSynchronize(h->ev_out[st]));
-    char* o = h->pin_out[st];
-    const size_t rows = (size_t)h->cap_rows;
+    char* o = h->pin_out[st] + 64;
+    const size_t rows = block_rows(nb);
     if (*h->pin_sat[st] != h->sat_seen[st]) {
       // f16x2 range guard: the signal branch of this stage left the f16 range (a spike sample, a tiny MAD, a
       // NaN).  Its inputs are still in staging set si (a set is reused three stages later): run the stage
@@ -1660,7 +1627,7 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
       int rc2 = run_stage(nb, si, st);
       h->h2 = h2; h->split = split;
       if (rc2) return rc2;
-      HIPCHK(h, hipMemcpyAsync(o, h->d_out[st], rows * kOutBytes + sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(h->pin_out[st], h->d_out[st], 64 + rows * kOutBytes, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       h->sat_seen[st] = *h->pin_sat[st];
       h->sat_reruns += 1;
@@ -1714,7 +1681,7 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     if (trace2 && tev.size() < 128) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); HIPCHK(h, hipEventRecord(e, h->stream)); tev.push_back(e); }
     HIPCHK(h, hipEventRecord(h->ev_done[st], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, h->ev_done[st], 0));
-    HIPCHK(h, hipMemcpyAsync(h->pin_out[st], h->d_out[st], (size_t)h->cap_rows * kOutBytes + sizeof(unsigned), hipMemcpyDeviceToHost, h->d2h_stream));
+    HIPCHK(h, hipMemcpyAsync(h->pin_out[st], h->d_out[st], 64 + block_rows(nb) * kOutBytes, hipMemcpyDeviceToHost, h->d2h_stream));
     HIPCHK(h, hipEventRecord(h->ev_out[st], h->d2h_stream));
     if (g >= 1 && (rc = finalize(prev_s, prev_nb, (int)((g - 1) % nrv_handle::kIn), st ^ 1))) return rc;
     prev_s = s;
@@ -1741,6 +1708,7 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
     fprintf(stderr, "[nrv host trace] %lld windows, %d stages: register %.3f ms (sig %d, feat %d), pipeline %.3f ms, unregister %.3f ms\n",
             (long long)n, (int)g, ms_reg, (int)direct_s, (int)direct_f, ms_run, since(t_u));
   }
+  h->host_call_open = false;
   return NRV_OK;
 }
 

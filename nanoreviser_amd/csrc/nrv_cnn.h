@@ -114,7 +114,7 @@ __device__ __forceinline__ void conv_positions(const float* __restrict__ cw, con
 // more than twice: wave (nh, kh) holds its 13 (12) k-blocks of split weights in registers, the kh = 1
 // wave hands its partial tile to its partner through a double-buffered 4 KB LDS slab, and the
 // partner adds it one iteration later (behind the tile barrier that exists anyway).
-// The f16x2 mode has its own signal-branch kernel (cnn_h2_kernel, nrv_cnn_f16x2.h).
+// The f16x2 mode has its own signal-branch kernel (cnn_r_kernel, nrv_cnn_r.h).
 template <bool SPLIT>
 __global__ void __launch_bounds__(kCnnThreads) cnn_kernel(const CnnArgs args) {
   constexpr int PLANE = 32 * 4 + 4;         // floats per kq plane of the image (+4: conflict-free)

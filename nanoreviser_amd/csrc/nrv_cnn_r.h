@@ -4,12 +4,12 @@
 #include "nrv_common.h"
 #include "nrv_lstm_f16x2s.h"   // f16x8, mfma16_f16
 #include "nrv_lstm1.h"         // lstm1_unit: the 6 -> 16 Bi-LSTM rides along as four more waves
-#include "nrv_lstm2_t.h"       // lstm2_t_unit: ... and, in the FRONT form, the 32 -> 64 Bi-LSTM behind it
 
 namespace nrv {
 
 // ---------------------------------------------------------------------------------------
-// cnn_r_kernel.  nanorevcnn.py:17-38 + output_handeler.py:209-215, as cnn_h2_kernel / cnn_m_kernel computed them.
+// cnn_r_kernel.  nanorevcnn.py:17-38 + output_handeler.py:209-215.
+// (cnn_h2_kernel / cnn_m_kernel below are round 3's forms of it, removed since.)
 //
 // What was measured on those (scripts/gpu_variants.py, parts compiled out, r03): with the 8 -> 8 convolution on the
 // matrix pipe the conv role needs 7 us per launch, the 400 -> 64 layer's MFMAs 18 us - and the launch takes 75 us,
@@ -56,7 +56,6 @@ struct CnnRModelParams {
   const void* dfrag;       // dense A operand x 2^10: [ks 13][mt 4][term 2][64 lanes][8 f16]
   const float* dbias;      // [64] x 2^16
   float* out;              // S x 2^6 as f16 split planes: window-major [wtile][t][16 chunks][32][8 f16] or event-major
-  const float* c1tab;      // conv1 on the matrix pipe (NRV_CNNR_C1MFMA): [64 lanes][16]: A operand, -, -, -, bias 4, s1 x 2^6 4, h1 x 2^6 4
 };
 struct CnnRArgs {
   CnnRModelParams m[2];
@@ -66,34 +65,9 @@ struct CnnRArgs {
   unsigned* sat;           // range guard counter
   Lstm1ModelParams l1[2];  // the 6 -> 16 Bi-LSTM of the same launch group (rows = windows)
   int l1_T, l1_rows;
-  Lstm2TModelParams l2[2]; // FRONT form: the 32 -> 64 Bi-LSTM behind it
 };
 
-#ifndef NRV_FEXP
-#define NRV_FEXP 0                                   // timing experiments on the FRONT form: 1 no read branch, 2 no 6 -> 16, 4 no conv units
-#endif
-#ifndef NRV_CNNR_MED3
-#define NRV_CNNR_MED3 1
-#endif
-#ifndef NRV_CNNR_MIX
-#define NRV_CNNR_MIX 1
-#endif
-#ifndef NRV_CNNR_SGB
-#define NRV_CNNR_SGB 1
-#endif
-#ifndef NRV_CNNR_WAVES
-#define NRV_CNNR_WAVES 8
-#endif
-#ifndef NRV_CNNR_PIPE
-#define NRV_CNNR_PIPE 1                                // 1: both conv2 triples of a k-step in front of both epilogues (r05: 47.2 -> 46.2 us, 620 -> 320 hazard-nop cycles per unit); 0: triple, epilogue, triple, epilogue
-#endif
-#ifndef NRV_CNNR_C1SGB
-#define NRV_CNNR_C1SGB 2                               // vector instructions behind each MFMA of a k-step's conv1 / dense interleave
-#endif
-#ifndef NRV_CNNR_C1MFMA
-#define NRV_CNNR_C1MFMA 0                              // 1: conv1 as v_mfma_f32_16x16x4_f32 (im2col on the B operand, r05: bit-identical, 1.5 us SLOWER); 0: on the VALU
-#endif
-constexpr int kCnnRWaves = NRV_CNNR_WAVES;             // conv / dense waves
+constexpr int kCnnRWaves = 8;                           // conv / dense waves
 constexpr int kCnnRL1Waves = 4;                         // 6 -> 16 Bi-LSTM waves
 constexpr int kCnnRThreads = 64 * (kCnnRWaves + kCnnRL1Waves);
 constexpr float kCnnRImgScale = 64.0f;                  // 2^6
@@ -110,20 +84,10 @@ typedef __attribute__((address_space(3))) float lds_f32r;
 // the conv1 code has no branch and stays in one basic block with the MFMAs it is interleaved with), shared by all waves.
 constexpr int kCnnRRing = 12, kCnnRSlot = 2 * 16 * 8, kCnnRC1Wave = kCnnRRing * kCnnRSlot;   // f16
 
-// FRONT = true: the whole front of the network in one launch.  Four conv / dense waves (their dense fragments come
-// from L2, one k-step ahead, instead of LDS) and four READ-BRANCH waves per workgroup, each of which runs, for its
-// 16 windows, the 6 -> 16 layer in both directions and then one direction (blockIdx.x & 1) of the 32 -> 64 layer
-// (lstm2_t_unit, whose 112 KB of weights and bias image take the LDS the dense fragments had).  The 6 -> 16 layer is
-// computed twice (once per direction workgroup; identical values to identical addresses): that is what lets X1 stay
-// inside the wave - no dependency between workgroups.
-constexpr int kFrontConvWaves = 4, kFrontThreads = 64 * (kFrontConvWaves + kCnnRL1Waves);
-template <int ACT, bool FRONT = false>
-__global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_kernel(const CnnRArgs args) {
+template <int ACT>
+__global__ void __launch_bounds__(kCnnRThreads) cnn_r_kernel(const CnnRArgs args) {
   constexpr int NKS = 13;
-  constexpr int kCnnRWaves = FRONT ? kFrontConvWaves : nrv::kCnnRWaves;
-  constexpr int kCnnRThreads = FRONT ? kFrontThreads : nrv::kCnnRThreads;
-  // dense fragments (104 KiB), or the 32 -> 64 layer's weights (96 KiB) + bias image (16 KiB)
-  __shared__ __attribute__((aligned(16))) float wd_s[FRONT ? kL2tWFrags * 256 + 16 * 256 : NKS * 4 * 2 * 256];
+  __shared__ __attribute__((aligned(16))) float wd_s[NKS * 4 * 2 * 256];          // dense fragments (104 KiB)
   __shared__ __attribute__((aligned(16))) _Float16 c1_s[kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot];  // 6 KiB per wave + 1
   __shared__ __attribute__((aligned(16))) float l1h_s[kCnnRL1Waves][16 * 16 + 16];  // lstm1_unit's wave-private images
   const CnnRModelParams& P = args.m[blockIdx.y];
@@ -134,42 +98,20 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
   const int n = lane & 15, q = lane >> 4;
 
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.dfrag, NKS * 8 * 1024);
-  if constexpr (FRONT) {
-    lstm2_t_stage(args.l2[blockIdx.y], blockIdx.x & 1, wd_s, wd_s + kL2tWFrags * 256, threadIdx.x, kCnnRThreads);
-    for (int i = threadIdx.x; i < kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot; i += kCnnRThreads) c1_s[i] = (_Float16)0.f;
-  } else {
-    for (int base = 0; base < NKS * 8 * 64; base += 8 * kCnnRThreads) {
-      f32x4 v[8];
+  for (int base = 0; base < NKS * 8 * 64; base += 8 * kCnnRThreads) {
+    f32x4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = buf_load16(wrs, (unsigned)(base + j * kCnnRThreads + threadIdx.x) * 16, 0);
+    for (int j = 0; j < 8; ++j) v[j] = buf_load16(wrs, (unsigned)(base + j * kCnnRThreads + threadIdx.x) * 16, 0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (base + j * kCnnRThreads + threadIdx.x < NKS * 8 * 64) ((f32x4*)wd_s)[base + j * kCnnRThreads + threadIdx.x] = v[j];
-    }
-    static_assert((kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot) % 8 == 0, "ring image in 16-byte pieces");
-    for (int i = threadIdx.x; i < (kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot) / 8; i += kCnnRThreads) ((f32x4*)c1_s)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // incl. the zero slot
+    for (int j = 0; j < 8; ++j)
+      if (base + j * kCnnRThreads + threadIdx.x < NKS * 8 * 64) ((f32x4*)wd_s)[base + j * kCnnRThreads + threadIdx.x] = v[j];
   }
+  static_assert((kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot) % 8 == 0, "ring image in 16-byte pieces");
+  for (int i = threadIdx.x; i < (kCnnRWaves * kCnnRC1Wave + 2 * kCnnRSlot) / 8; i += kCnnRThreads) ((f32x4*)c1_s)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // incl. the zero slot
   __syncthreads();                                   // the only barrier: from here on the waves are independent
 
   if (wave >= kCnnRWaves) {
     // ================================ 6 -> 16 Bi-LSTM role ====================================
-    if constexpr (FRONT) {
-      // ======================= whole read branch: 6 -> 16 both directions, then 32 -> 64 ====================
-      const int nrb = (args.l1_rows + 15) / 16, rw = wave - kCnnRWaves;
-      for (int rb = (blockIdx.x >> 1) * kCnnRL1Waves + rw; rb < ((NRV_FEXP & 1) ? 0 : nrb); rb += (gridDim.x >> 1) * kCnnRL1Waves) {
-#if NRV_FEXP & 2                                     // 2: no 6 -> 16 layer in the chain
-        if (rb < 0)
-#endif
-        lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, 0, rb, lane, l1h_s[rw]);
-#if NRV_FEXP & 2
-        if (rb < 0)
-#endif
-        lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, 1, rb, lane, l1h_s[rw]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X1 of these 16 windows is in L2; this wave reads it back
-        lstm2_t_unit<ACT, true>(args.l2[blockIdx.y], args.l1_T, blockIdx.x & 1, rb, lane, wd_s, wd_s + kL2tWFrags * 256);
-      }
-      return;
-    }
     const int nu = 2 * ((args.l1_rows + 15) / 16);   // units: (16-row block, direction)
     for (int idx = blockIdx.x * kCnnRL1Waves + (wave - kCnnRWaves); idx < nu; idx += gridDim.x * kCnnRL1Waves)
       lstm1_unit<ACT, true>(args.l1[blockIdx.y], args.l1_T, args.l1_rows, idx & 1, idx >> 1, lane, l1h_s[wave - kCnnRWaves]);
@@ -199,17 +141,9 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
 #define h1v K.h1
   // ReLU of a matrix-instruction result as v_med3_f32(x, 0, 3e38): written as fmaxf, hipcc puts a canonicalising
   // v_max_f32 x, x in front of every v_max_f32 0, x (104 extra instructions per unit).
-#if NRV_CNNR_MED3
   auto relu_acc = [](float x) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f); };
-#else
-  auto relu_acc = [](float x) __attribute__((always_inline)) { return __builtin_fmaxf(x, 0.f); };
-#endif
-#if NRV_CNNR_MIX
   float m1; asm("s_mov_b32 %0, 0xbf800000" : "=s"(m1));   // -1, opaque: x - (float)hi as v_fma_mix_f32 (no v_cvt_f32_f16)
 #define NRV_LO(x, h) __builtin_fmaf((float)(h), m1, (x))
-#else
-#define NRV_LO(x, h) ((x) - (float)(h))
-#endif
   // Ring slot of position pos: pos % 12.  A quarter's positions C + q never wrap for C % 12 <= 8, so the slot is an
   // immediate offset on ONE per-lane address (rq); the two bases that can wrap (C % 12 = 9, 11) have their own.
   lds_h* const rq = c1 + q * kCnnRSlot + n * 8;
@@ -221,11 +155,7 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     return cm == 9 ? rq9 : cm == 11 ? rq11 : rq + cm * kCnnRSlot;
   };
 
-#if (NRV_EXP & 1) || (NRV_FEXP & 4)                  // timing experiments (results wrong): 1 no units at all
-  const int n_units = 0;
-#else
   const int n_units = 2 * args.n_tiles;
-#endif
   // conv1 + BatchNorm of one position (this lane's event) from its three samples -> ring slot d, both terms.
   // (Written as packed f32 math, v_pk_fma_f32, it was measured SLOWER, 73 vs 67 us.)
   // Range guard of c1: a conv1 output beyond 65504 / 2^6 would become hi = +inf, lo = -inf, their products
@@ -235,13 +165,8 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
   // This guard covers FINITE overflow only: v_med3_f32 returns min3 when an operand is NaN, so a NaN sample drops out
   // of xmax (and +Inf is clamped to 3e38, still above every bound).  NaN samples are caught by the check on S, which a
   // NaN always reaches through conv2 and the dense layer (tests/test_gpu_range.py::test_nan_and_inf_samples pins both).
-#if !NRV_CNNR_C1MFMA
   float xmax = 0.f;
-#endif
   auto conv1_store = [&](lds_h* d, float xm, float xc, float xp) __attribute__((always_inline)) {
-#if NRV_CNNR_C1MFMA
-    (void)d; (void)xm; (void)xc; (void)xp;
-#else
     xmax = __builtin_amdgcn_fmed3f(__builtin_fabsf(xc), xmax, 3.0e38f);
     float c[8];
 #pragma unroll
@@ -263,42 +188,8 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     }
     *(lds_h8*)d = hi;
     *(lds_h8*)(d + 16 * 8) = lo;
-#endif
   };
 
-#if NRV_CNNR_C1MFMA
-  // conv1 on the matrix pipe (north_star: "conv1d ... lowered to im2col + MFMA GEMM"; nanorevcnn.py:24, 30): ONE
-  // v_mfma_f32_16x16x4_f32 gives the 8 channels of TWO positions of 16 events.  The B operand IS the im2col column:
-  // lane (event n, k = q) holds sample x[P - 1 + q], four consecutive samples of the event.  A [16][4]: rows 0-7 = channel
-  // co of position P (taps k = 0..2, k = 3 zero), rows 8-15 = channel co of position P + 1 (taps k = 1..3, k = 0 zero);
-  // C = the bias.  f32 in, f32 accumulate, k in order: bit for bit the fmaf chain b + x[p-1] w0 + x[p] w1 + x[p+1] w2 of
-  // the VALU form (the zero weight adds +-0).  Lane (n, q) receives channels 4 (q & 1) .. + 3 of position P + (q >> 1):
-  // ReLU, BatchNorm, split, and 8 bytes per term into the ring slot of that position.
-  const f32x4 k1a = *(const f32x4*)(P.c1tab + lane * 16);           // [0]: the A operand
-  const f32x4 k1b = *(const f32x4*)(P.c1tab + lane * 16 + 4);
-  const f32x4 k1s = *(const f32x4*)(P.c1tab + lane * 16 + 8);
-  const f32x4 k1h = *(const f32x4*)(P.c1tab + lane * 16 + 12);
-  typedef __attribute__((address_space(3))) f16x4r lds_h4;
-  lds_h* const rqh = c1 + (q >> 1) * kCnnRSlot + n * 8 + 4 * (q & 1);          // position P + (q >> 1), P even: never wraps
-  lds_h* const wslot = (lds_h*)c1_s + kCnnRWaves * kCnnRC1Wave + kCnnRSlot + n * 8 + 4 * (q & 1);   // the write-only slot
-  float xmax = 0.f;
-  // positions P, P + 1 (P even, compile-time) from xb = x[P - 1 + q] of this lane's event
-  auto conv1_mfma = [&](int Pp, float xb) __attribute__((always_inline)) {
-    xmax = __builtin_amdgcn_fmed3f(__builtin_fabsf(xb), xmax, 3.0e38f);
-    const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1a[0], xb, k1b, 0, 0, 0);
-    float c[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(relu_acc(acc[r]), k1s[r], k1h[r]);
-    const f16x2r h01 = __builtin_convertvector(f32x2r{c[0], c[1]}, f16x2r);
-    const f16x2r h23 = __builtin_convertvector(f32x2r{c[2], c[3]}, f16x2r);
-    const f16x2r l01 = __builtin_convertvector(f32x2r{NRV_LO(c[0], h01[0]), NRV_LO(c[1], h01[1])}, f16x2r);
-    const f16x2r l23 = __builtin_convertvector(f32x2r{NRV_LO(c[2], h23[0]), NRV_LO(c[3], h23[1])}, f16x2r);
-    lds_h* d = rqh + (Pp % kCnnRRing) * kCnnRSlot;
-    if (Pp + 1 >= kSig) d = (Pp + (q >> 1) < kSig) ? d : wslot;      // a position past the window: not into the ring
-    *(lds_h4*)d = f16x4r{h01[0], h01[1], h23[0], h23[1]};
-    *(lds_h4*)(d + 16 * 8) = f16x4r{l01[0], l01[1], l23[0], l23[1]};
-  };
-#endif
 
   // units of 16 events: unit u = 2 * tile + sub
   // Units are dealt WORKGROUP-first (unit u -> workgroup u % G, then that workgroup's waves in turn): the bench step's
@@ -331,17 +222,6 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     // (Fetching the NEXT unit's first samples in this unit's last two k-steps, which load nothing useful, was built
     // and measured: 73 us instead of 65.)
     float xa[3], xres[2];
-#if NRV_CNNR_C1MFMA
-    {
-      // x[P - 1 + q] for P = 0, 2 (set 0) now, for P = 4, 6 (set 1) in flight
-      const float xb0 = buf_load4(rs, rok && q > 0 ? xq - 4u : kOut, 0), xb1 = ldq(1);
-      xa[0] = ldq(3); xa[1] = ldq(5); xa[2] = 0.f;
-#pragma unroll
-      for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(2 * pi);
-      conv1_mfma(0, xb0);
-      conv1_mfma(2, xb1);
-    }
-#else
     {
       const float x0 = buf_load4(rs, rok && q > 0 ? xq - 4u : kOut, 0), x1 = ldq(0), x2 = ldq(1);
 #pragma unroll
@@ -350,7 +230,6 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
       for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(2 * pi);
       conv1_store(slot_c(0), x0, x1, x2);
     }
-#endif
 
     f32x4 S[4];
 #pragma unroll
@@ -366,13 +245,9 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const f16x8 w_hi = __builtin_bit_cast(f16x8, wf[mt][0]), w_lo = __builtin_bit_cast(f16x8, wf[mt][1]);
-#if NRV_EXP & 4                                      // 4: no dense MFMAs
-        S[mt][0] += (float)w_hi[0] + (float)w_lo[0] + (float)fb_hi[mt] + (float)fb_lo[mt];
-#else
         S[mt] = mfma16_f16(w_hi, fb_hi, S[mt]);
         S[mt] = mfma16_f16(w_hi, fb_lo, S[mt]);
         S[mt] = mfma16_f16(w_lo, fb_hi, S[mt]);
-#endif
       }
     };
     // The 13 k-steps are UNROLLED: every position is then a compile-time constant + q, so ring slots and sample
@@ -380,37 +255,18 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
     // (0, 10, 11, 12).  As a rolled loop the same body spent ~60 of its ~200 vector instructions per k-step on
     // pos % 10, range compares and selects.
 #pragma unroll
-    for (int ks = 0; ks < ((NRV_EXP & 2) ? 1 : NKS); ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       // The dense products of k-step ks - 1 go FIRST: they depend on nothing computed in this iteration, and the
       // conv1 arithmetic below is interleaved with them (one MFMA, three vector instructions, ...): measured with
       // parts compiled out, the MFMAs at the END of a k-step added their full pipe time to the launch (12.6 us).
       dense();                                         // (k-step "-1": zero fragments)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {                 // this k-step's dense weights (used at the top of the next iteration)
-        if constexpr (FRONT) {
-          wf[mt][1] = buf_load16(wrs, (unsigned)lane * 16, (unsigned)(((ks * 4 + mt) * 2 + 1) * 1024));
-          wf[mt][0] = buf_load16(wrs, (unsigned)lane * 16, (unsigned)(((ks * 4 + mt) * 2) * 1024));
-        } else {
-          wf[mt][1] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2 + 1) * 256);
-          wf[mt][0] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2) * 256);
-        }
+        wf[mt][1] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2 + 1) * 256);
+        wf[mt][0] = *(const f32x4*)(wd + ((ks * 4 + mt) * 2) * 256);
       }
       // conv1 of the NEXT set (positions 4 ks + 4 .. + 7; pair B below needs its first position), samples one step ahead
       const float xr0 = xres[0] * kCnnRImgScale, xr1 = xres[1] * kCnnRImgScale;
-#if NRV_CNNR_C1MFMA
-      {
-        const float xb0 = xa[0], xb1 = xa[1];
-        xa[0] = ldq(4 * (ks + 2) - 1);
-        xa[1] = ldq(4 * (ks + 2) + 1);
-        if (ks + 1 < NKS) {
-#pragma unroll
-          for (int pi = 0; pi < 2; ++pi) xres[pi] = ldh(4 * (ks + 1) + 2 * pi);
-        }
-        const int C = 4 * (ks + 1);                    // positions C .. C + 3
-        if (C < kSig) conv1_mfma(C, xb0);
-        if (C + 2 < kSig) conv1_mfma(C + 2, xb1);
-      }
-#else
       {
         const float x0 = xa[0], x1 = xa[1], x2 = xa[2];
 #pragma unroll
@@ -423,29 +279,15 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
         if (C < kSig) {
           lds_h* d = slot_c(C);
           if (C + 3 >= kSig) d = q < kSig - C ? d : zslot + kCnnRSlot;
-#if !(NRV_EXP & 16)                                  // 16: no conv1 in the loop
           conv1_store(d, x0, x1, x2);
-#else
-          if (x0 + x1 + x2 == 1.2345f) conv1_store(d, x0, x1, x2);
-#endif
         }
       }
-#endif
-#if NRV_CNNR_SGB && NRV_CNNR_C1MFMA
-#pragma unroll
-      for (int i = 0; i < 14; ++i) {                         // 12 dense products + the two conv1 products, ~30 vector instructions
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, NRV_CNNR_C1SGB, 0);
-      }
-#elif NRV_CNNR_SGB
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
       }
-#endif
       wave_lds_fence();                                // other quarters' conv1 results -> this lane's fragment reads
-#if NRV_CNNR_PIPE
       // both position pairs' conv2 triples FIRST, then both epilogues: the epilogue of pair 0 no longer waits (s_nop 9) for the
       // matrix result it reads - the other pair's three products stand in between
       f32x4 acc2[2];
@@ -478,41 +320,6 @@ __global__ void __launch_bounds__(FRONT ? kFrontThreads : kCnnRThreads) cnn_r_ke
         }
       }
     }
-#else
-#pragma unroll
-      for (int pi = 0; pi < 2; ++pi) {
-        const int p = 4 * ks + 2 * pi;                 // this triple gives positions p, p + 1
-        // B operand: k-group q = tap q, i.e. c1 at position p + q - 1 (zero padding outside the window)
-        const lds_h* src = slot_c(p - 1);
-        if (p - 1 < 0) src = q > 0 ? src : zslot;
-        if (p - 1 + 3 >= kSig) src = q < kSig - (p - 1) ? src : zslot;
-        const f16x8 b_lo = *(const lds_h8*)(src + 16 * 8);
-        const f16x8 b_hi = *(const lds_h8*)src;
-        // ---- conv2: positions p (rows 0-7) and p + 1 (rows 8-15) of 16 events
-        f32x4 acc = binit;
-#if NRV_EXP & 8                                      // 8: no conv2 MFMAs
-        acc[0] += (float)b_hi[0] + (float)b_lo[1];
-#else
-        acc = mfma16_f16(a2_hi, b_hi, acc);
-        acc = mfma16_f16(a2_hi, b_lo, acc);
-        acc = mfma16_f16(a2_lo, b_hi, acc);
-#endif
-        // ---- bias is in, ReLU, BatchNorm, + sample (x 2^6), split: elements 4 pi .. 4 pi + 3 of the dense B fragment
-        // (this lane: position p + (q >> 1); positions 50, 51 of the last k-step meet zero weights)
-        const float xs = pi ? xr1 : xr0;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(relu_acc(acc[r]), k1[r], k2[r] + xs);
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const f16x2r hp = __builtin_convertvector(f32x2r{v[r], v[r + 1]}, f16x2r);
-          fb_hi[4 * pi + r] = hp[0]; fb_hi[4 * pi + r + 1] = hp[1];
-          const f16x2r lp = __builtin_convertvector(f32x2r{NRV_LO(v[r], hp[0]), NRV_LO(v[r + 1], hp[1])}, f16x2r);
-          fb_lo[4 * pi + r] = lp[0]; fb_lo[4 * pi + r + 1] = lp[1];
-        }
-      }
-    }
-#endif
     dense();                                           // the last k-step's products
     // ---- S x 2^6 as f16 split planes: output features 16 mt + 4 q .. + 3 of event n = 8 bytes per term
     float* dst = P.out + (size_t)b * 16 * 128 + (q >> 1) * 128 + (16 * sub + n) * 4 + (q & 1) * 2;

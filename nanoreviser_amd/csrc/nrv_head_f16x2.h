@@ -43,12 +43,6 @@ struct HeadH2Args {
   int n_tiles;
 };
 
-#ifndef NRV_HEAD_XRING
-#define NRV_HEAD_XRING 0      // 1: the next unit's k-block requested inside dense1's k-loop (r05: 27.0 vs 26.3 us, worse)
-#endif
-#ifndef NRV_HEAD_EARLYX
-#define NRV_HEAD_EARLYX 1
-#endif
 constexpr int kHeadH2Threads = 512;         // eight waves: two per SIMD, the T units of a tile in two rounds
 
 __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Args args) {
@@ -87,7 +81,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
     else if (tid >= 320 && tid < 320 + 16 * C0) tl[24 + tid - 320] = P.outw[tid - 320];
   }
   for (int i = tid; i < 16 * T * 2; i += NT) ((f32x4*)fw8)[i] = ((const f32x4*)P.featw)[i];   // one 16-byte copy per thread at T <= 16
-  // the first unit's inputs are requested BEHIND the staging requests and in front of the barrier (NRV_HEAD_EARLYX): they travel
+  // the first unit's inputs are requested BEHIND the staging requests and in front of the barrier: they travel
   // while the workgroup meets.  (In FRONT of the staging requests they delayed the weights: r03, 25.5 vs 24.8 us.)
   const unsigned av = l31 * 16 + half * 512;                   // chunk 4*kb + 2*term + half, row l31
   auto load_x = [&](int u, f32x4 (&x)[8][2]) __attribute__((always_inline)) {
@@ -99,9 +93,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
     }
   };
   f32x4 x[8][2];
-#if NRV_HEAD_EARLYX
   if (wave < T && (int)blockIdx.x < args.n_tiles) load_x(blockIdx.x * T + wave, x);
-#endif
   __syncthreads();
 
   const float m1 = neg_one_opaque();
@@ -130,7 +122,7 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
 
   for (int tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
     // ---- per-timestep MLP: wave w takes timesteps w, w + 8, ...
-    if (wave < T && (!NRV_HEAD_EARLYX || tile != (int)blockIdx.x)) load_x(tile * T + wave, x);
+    if (wave < T && tile != (int)blockIdx.x) load_x(tile * T + wave, x);
     for (int t = wave; t < T; t += NW) {
       f32x16 acc[4];
 #pragma unroll
@@ -148,21 +140,10 @@ __global__ void __launch_bounds__(kHeadH2Threads) head_h2_kernel(const HeadH2Arg
         for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_f16(w[mt][PW[pr]], xs[PX[pr]], acc[mt]);
-#if NRV_HEAD_XRING
-        // the next unit's k-block kb is requested as soon as this unit's has been multiplied: it has the rest of dense1 and the
-        // two small layers to arrive (requested behind dense1, only the small layers' ~0.7 us covered an HBM access)
-        if (t + NW < T) {
-          const __amdgpu_buffer_rsrc_t nrs = make_rsrc(P.in + (size_t)(tile * T + t + NW) * 32 * 128, 32 * 128 * 4);
-          x[kb][0] = buf_load16(nrs, av, kb * 2048);
-          x[kb][1] = buf_load16(nrs, av, kb * 2048 + 1024);
-        }
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
-#if !NRV_HEAD_XRING
       // the next unit's inputs travel while the two small layers run
       if (t + NW < T) load_x(tile * T + t + NW, x);
-#endif
       // dense2: 128 -> 32; k-block kb takes registers 8*(kb&1).. of tile kb>>1 (two accumulators: the 24
       // products would otherwise form one dependent chain)
       f32x16 a2[2];

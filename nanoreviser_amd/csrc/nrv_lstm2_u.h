@@ -1,35 +1,78 @@
 // Second read-branch layer, Bi-LSTM(32 -> 64), f16x2 mode: transposed products, TWO waves per chain (r05).
 #pragma once
-#include "nrv_lstm2_t.h"   // Lstm2TArgs, lstm2_t_stage: same weight / bias images, same packing
+#include "nrv_lstm_f16x2s.h"   // mfma16_f16
 
 namespace nrv {
 
 // ---------------------------------------------------------------------------------------
 // lstm2_u_kernel.  output_handeler.py:220 (Bidirectional(LSTM(64)) on the 32 features of read_rnn1).
 //
-// lstm2_t_kernel runs one wave per 16-row chain and 4096 windows x 2 directions x 2 models are exactly 1024 chains: ONE
-// wave per SIMD.  A wave alone issues a vector instruction every 4 cycles (the SIMD takes one every 2 from two waves:
-// MI355X_MICROARCH.md "vector-instruction ISSUE cost"), and a step of that wave is 533 vector instructions + 144 matrix
-// instructions + 96 LDS reads in ONE instruction stream: 5.5 k cycles for 2.4 k of matrix pipe (r04 PMC: pipe 30 % busy).
+// The layer is small (10.5 GFLOP per 4096-window group, 98 KB of f16x2 weights per direction) and was LATENCY-bound with
+// hidden units on the lanes (round 2: 44-48 us, matrix pipe 27 % busy).  Here the products are TRANSPOSED,
+// z^T = [W | U]^T [x ; h]: the weights are the A operand (M = the 256 gate-units), the activations the B operand (N = 16 data
+// rows), so a result tile has the data row on the lane and the gate-units in the registers: tile (gate g, unit tile ut) of
+// v_mfma_f32_16x16x32_f16 gives lane l = (row n = l & 15, q = l >> 4) the units 16 ut + 4 q + r, r = 0..3; i, f, g, o of a
+// (row, unit) meet in one lane, c never leaves the lane, and the values of h_t a lane computes are - as two f16x8 terms,
+// elements 8 kb + j = unit 16 (2 kb + (j >> 2)) + 4 q + (j & 3) - B fragments of the next step's recurrent k-blocks: the host
+// packs the rows of U in that k order (pack_lstm2_t).
+//   * weights: the whole f16x2 set of one (direction, model), [kb 3][tile 16][term 2] fragments of 1 KiB (96 KiB), is copied
+//     to LDS once per workgroup and every wave streams its half from there each step; the bias enters as the initial value of
+//     the accumulators, read from a [tile][lane] image (16 KiB);
+//   * output: h x 2^13 as f16 split planes, RAW - the BatchNorm(128) behind this layer lives in the weights of the 192->128
+//     layer's first 128 input rows (nrv_api.hip upload_model) - each lane's 4 units of a unit tile are 8 contiguous bytes.
+//
+// Round 4's form (lstm2_t_kernel, removed in r06; HISTORY.md) ran one wave per 16-row chain: 4096 windows x 2 directions x 2
+// models are exactly 1024 chains, ONE wave per SIMD, 533 vector + 144 matrix instructions + 96 LDS reads per step in one
+// instruction stream: 5.5 k cycles for 2.4 k of matrix pipe.
 //
 // Here a chain is TWO waves on one SIMD (wave w and w + 4 of an 8-wave workgroup): wave `hf` owns unit tiles 2 hf and
 // 2 hf + 1 - 32 hidden units x 4 gates = 8 accumulator tiles, 8 cell states per lane - and therefore k-block hf of h_t (the
-// host packs U's rows so that k-block kb holds unit tiles 2 kb, 2 kb + 1: lstm2_t_kernel's layout, unchanged).  The two
+// host packs U's rows so that k-block kb holds unit tiles 2 kb, 2 kb + 1).  The two
 // halves of h_t meet in LDS: each wave stores its two f16x8 terms (32 B per lane), ONE workgroup barrier, each reads both
 // halves back as the B fragments of the next step's recurrent product - 2 KiB per chain and step through a double-buffered
-// 16 KiB image, on top of the 96 + 16 KiB of weights and bias.  Everything else is lstm2_t_kernel's: i, f, g, o of a
+// 16 KiB image, on top of the 96 + 16 KiB of weights and bias.  As in the one-wave form: i, f, g, o of a
 // (row, unit) in one lane, c in registers, the gates of a unit tile between the products of the next one, the input
-// projection of step s+1 behind the recurrent product of step s, products in the same order - results BIT-IDENTICAL.
+// projection of step s+1 behind the recurrent product of step s, products in the same order - results bit-identical to it.
 // While one wave of the SIMD does gate arithmetic the other feeds the matrix pipe.
 // grid = (ceil(rows / 64), 2 directions, 2 models), block = 512: four chains of two waves.
 // ---------------------------------------------------------------------------------------
 constexpr int kL2uThreads = 512;
-#ifndef NRV_L2U_ILP
-#define NRV_L2U_ILP 0      // 1: gate pieces stage-major over the four elements of a unit tile (independent neighbours; r05: 35.3-36.0 vs 34.9-35.7 us, nothing); 0: element-major
-#endif
-#ifndef NRV_L2U_EXP
-#define NRV_L2U_EXP 0      // timing experiments (results WRONG): 1 no barrier in the exchange, 2 no gate arithmetic, 4 no matrix products
-#endif
+
+struct Lstm2TModelParams {
+  const void* wfrag;      // [dir][kb 3 (input, rec 0, rec 1)][tile 16][term 2][64 lanes][8 f16], x 2^(E - s)
+  const float* bias;      // [dir][tile 16][64 lanes][4], x 2^E, in accumulator layout
+  const float* in;        // X1 split planes [tile32][T][kb16 2][term][half][32][8 f16]
+  float* out;             // X2 split planes [tile32][T][kb16 8][term][half][32][8 f16], h x 2^13
+  float descale;          // 2^-E
+};
+struct Lstm2TArgs {
+  Lstm2TModelParams m[2];
+  int T;
+  int n_rows;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kL2tWFrags = 3 * 16 * 2;                 // 1 KiB fragments of one direction's weights
+
+// Staging of one (direction, model)'s weights and bias image into LDS, by all `nthreads` threads of the workgroup
+// (the caller puts a barrier behind it).
+__device__ __forceinline__ void lstm2_t_stage(const Lstm2TModelParams& P, const int dir, float* wl, float* bl,
+                                              const int tid, const int nthreads) {
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc((const char*)P.wfrag + (size_t)dir * kL2tWFrags * 1024, kL2tWFrags * 1024);
+  for (int base = 0; base < kL2tWFrags * 64; base += 8 * nthreads) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = buf_load16(wrs, (unsigned)(base + j * nthreads + tid) * 16, 0);   // past the end: 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (base + j * nthreads + tid < kL2tWFrags * 64) ((f32x4*)wl)[base + j * nthreads + tid] = v[j];
+  }
+  const f32x4* bsrc = (const f32x4*)(P.bias + (size_t)dir * 16 * 256);
+  for (int i = tid; i < 16 * 64; i += nthreads) ((f32x4*)bl)[i] = bsrc[i];
+}
+
 
 template <int ACT>
 __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const int T, const int dir, const int rb,
@@ -77,15 +120,11 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
 
   constexpr int GST = 13;
   struct GateSt { float zi, zf, zg, zo, cp, p, t; };
-  GateSt gsr[4];                                       // one per element of the unit tile in flight (stage-major order)
+  GateSt gsr;                                          // the element of the unit tile in flight
   float hv[4];
   auto gate_stage = [&](int u, int r, int st, int t_out) __attribute__((always_inline)) {
     const int e = 4 * u + r;
-    GateSt& gs = gsr[NRV_L2U_ILP ? r : 0];
-#if NRV_L2U_EXP & 2
-    if (st == 0) { hN[0][e] = (_Float16)Z[u][r]; hN[1][e] = (_Float16)Z[6 + u][r]; }
-    return;
-#endif
+    GateSt& gs = gsr;
     if (st == 0) { gs.zi = Z[0 + u][r]; gs.zf = Z[2 + u][r]; gs.cp = c[e]; }
     else if (st == 1) { gs.zg = Z[4 + u][r]; gs.zo = Z[6 + u][r]; }
     else if (st == 2) {
@@ -134,12 +173,9 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
       }
     }
   };
-  // piece pc (0 .. 4 GST - 1) of a unit tile: stage-major (pc = 4 st + r: the four elements' stages are independent neighbours, a
-  // dependent instruction is four pieces away) or element-major (pc = GST r + st: lstm2_t_kernel's order, one wave per SIMD)
-  auto gate_piece = [&](int u, int pc, int t_out) __attribute__((always_inline)) {
-    if (NRV_L2U_ILP) gate_stage(u, pc & 3, pc >> 2, t_out);
-    else gate_stage(u, pc / GST, pc % GST, t_out);
-  };
+  // piece pc (0 .. 4 GST - 1) of a unit tile, element-major: pc = GST r + st.  (Stage-major - the four elements' stages as
+  // independent neighbours - was measured in r05: 35.3-36.0 vs 34.9-35.7 us, nothing: the launch is issue-bound.)
+  auto gate_piece = [&](int u, int pc, int t_out) __attribute__((always_inline)) { gate_stage(u, pc / GST, pc % GST, t_out); };
   auto gates_plain = [&](int u, int t_out) __attribute__((always_inline)) {
 #pragma unroll
     for (int pc = 0; pc < 4 * GST; ++pc) {
@@ -160,11 +196,7 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {
         const f16x8 a = __builtin_bit_cast(f16x8, PA[pr] ? wr[ci % NR].lo : wr[ci % NR].hi);
-#if NRV_L2U_EXP & 4
-        Z[g * 2 + u][pr] += (float)a[0] + (float)hB[kb][PB[pr]][1];
-#else
         Z[g * 2 + u] = mfma16_f16(a, hB[kb][PB[pr]], Z[g * 2 + u]);
-#endif
         if (u > 0) {
           const int tk = (ci & 7) * 3 + pr;             // tick inside this unit tile: 0..23
 #pragma unroll
@@ -193,11 +225,7 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {
         const f16x8 a = __builtin_bit_cast(f16x8, PA[pr] ? wr[ci % NR].lo : wr[ci % NR].hi);
-#if NRV_L2U_EXP & 4
-        Z[g * 2 + u][pr] += (float)a[0] + (float)xb[PB[pr]][1];
-#else
         Z[g * 2 + u] = mfma16_f16(a, xb[PB[pr]], Z[g * 2 + u]);
-#endif
         if constexpr (GATES1) {
           const int tk = k * 3 + pr;                    // 0..23; the gates of unit tile 1 take ticks 0..11
           if (tk < 12) {
@@ -214,9 +242,7 @@ __device__ __forceinline__ void lstm2_u_unit(const Lstm2TModelParams& P, const i
     f32x4* const img = hx + p * 4 * 64 + lane;          // [kb 2][term 2][64 lanes]
     img[(hf * 2 + 0) * 64] = __builtin_bit_cast(f32x4, hN[0]);
     img[(hf * 2 + 1) * 64] = __builtin_bit_cast(f32x4, hN[1]);
-#if !(NRV_L2U_EXP & 1)
     __syncthreads();
-#endif
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

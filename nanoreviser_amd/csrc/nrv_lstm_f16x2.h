@@ -5,9 +5,6 @@
 // -DNRV_EXP=<bits> (tools/lstm_exp.sh D:...; 0 in the product): timing experiments that compile parts of cnn_r_kernel
 // out (nrv_cnn_r.h) - results WRONG by construction, only time means something, and even that only with care: the
 // chip's clock follows the kernel's power, which follows the DATA.
-#ifndef NRV_EXP
-#define NRV_EXP 0
-#endif
 namespace nrv {
 
 // ---------------------------------------------------------------------------------------

@@ -35,9 +35,6 @@ namespace nrv {
 #ifndef NRV_STAMP
 #define NRV_STAMP 0
 #endif
-#ifndef NRV_H2S_INCHAIN
-#define NRV_H2S_INCHAIN 2
-#endif
 #if NRV_STAMP
 constexpr int kStampSlots = 32, kStampSteps = 15, kStampWaves = 4, kStampBlocks = 256;
 __device__ unsigned long long nrv_stamp_buf[2][kStampBlocks][kStampWaves][kStampSteps][kStampSlots];
@@ -202,7 +199,7 @@ lstm_h2s_kernel(const LstmH2Args args) {
     d.v[1] = *(const f32x4*)(qh + TERM);                 // lo first, as for x
     d.v[0] = *(const f32x4*)(qh);
   };
-  // NRV_H2S_INCHAIN: one request at a time, issued BEHIND a product inside a chain of three instead of in front of the
+  // One request at a time, issued BEHIND a product inside a chain of three instead of in front of the
   // entry / block (tools/microbench/tick_cost.hip: two 1 KB requests in front of an entry's 12 products cost 2.3 cycles
   // per product, inside a chain 0.6; lstm_h2w_kernel is built that way)
   auto loadB1 = [&](int e, int term, BReg& bb) __attribute__((always_inline)) {
@@ -335,7 +332,6 @@ lstm_h2s_kernel(const LstmH2Args args) {
     for (int kk = 0; kk < KK_IN; ++kk) {
       if constexpr (WORK) NRV_STAMP_AT(8 + kk);
       const int ka = kk + LA;                            // activations LA blocks ahead: input, then recurrent
-#if NRV_H2S_INCHAIN != 1
       {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -344,14 +340,11 @@ lstm_h2s_kernel(const LstmH2Args args) {
           else loadA_in(xb_wrap, ka - KK_IN, rt, a[ka % NA][rt]);
         }
       }
-#endif
 #pragma unroll
       for (int ge = 0; ge < EPK; ++ge) {
         const int e = EPK * kk + ge, g = ge / UH, uh = ge % UH;
         const int en = WORK ? (e + LBG) % (EPK * KK) : (e + LBG) % (EPK * KK_IN);
-#if NRV_H2S_INCHAIN != 1
         loadB(en, b[(e + LBG) % NBG]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -360,23 +353,6 @@ lstm_h2s_kernel(const LstmH2Args args) {
             const int tk = (e * RT + rt) * 3 + pr;
             N[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]],
                                       (kk == 0 && pr == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : N[g][uh][rt]);
-#if NRV_H2S_INCHAIN == 1
-            {
-              const int m = rt * 3 + pr, pa = ge * APPE + (m - 4);
-              const bool fa = m >= 4 && m < 4 + APPE && pa < 2 * RT;
-              if (m < 2 || fa) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (m < 2) loadB1(en, m, b[(e + LBG) % NBG]);
-                if (fa) {
-                  const int rn = pa / 2, tn = pa % 2;
-                  if (ka < KK_IN) loadA_in1(xb, ka, rn, tn, a[ka % NA][rn]);
-                  else if (WORK) loadA_rec1(hp_next, ka - KK_IN, rn, tn, a[ka % NA][rn]);
-                  else loadA_in1(xb_wrap, ka - KK_IN, rn, tn, a[ka % NA][rn]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-#endif
             if constexpr (WORK) {
               if (tk < TG) {
 #pragma unroll
@@ -407,29 +383,16 @@ lstm_h2s_kernel(const LstmH2Args args) {
       const int kk = KK_IN + kr;
       NRV_STAMP_AT(1 + kr);
       const int ka = kk + LA;
-#if !NRV_H2S_INCHAIN
-      {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          if (ka < KK) loadA_rec(hp, ka - KK_IN, rt, a[ka % NA][rt]);
-          else loadA_in(xb_next, ka - KK, rt, a[ka % NA][rt]);
-        }
-      }
-#endif
 #pragma unroll
       for (int ge = 0; ge < EPK; ++ge) {
         const int e = EPK * kk + ge, g = ge / UH, uh = ge % UH;
         const int en = (e + LBG) % (EPK * KK);
-#if !NRV_H2S_INCHAIN
-        loadB(en, b[(e + LBG) % NBG]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int pr = 0; pr < 3; ++pr) {
             Z[g][uh][rt] = mfma16_f16(__builtin_bit_cast(f16x8, a[kk % NA][rt].v[PA[pr]]), b[e % NBG].t[PB[pr]], Z[g][uh][rt]);
-#if NRV_H2S_INCHAIN
             const int m = rt * 3 + pr, pa = ge * APPE + (m - 4);
             const bool fa = m >= 4 && m < 4 + APPE && pa < 2 * RT;
             if (m < 2 || fa) {
@@ -442,7 +405,6 @@ lstm_h2s_kernel(const LstmH2Args args) {
               }
               __builtin_amdgcn_sched_barrier(0);
             }
-#endif
           }
         __builtin_amdgcn_sched_barrier(0);
       }

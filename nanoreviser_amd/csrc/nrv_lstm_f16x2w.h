@@ -57,9 +57,6 @@ namespace nrv {
 #ifndef NRV_STAMP_REC_ENTRIES
 #define NRV_STAMP_REC_ENTRIES 0
 #endif
-#ifndef NRV_WS_DEFER
-#define NRV_WS_DEFER 1
-#endif
 #if NRV_STAMP
 // diagnostic build: [wave 8][step 15][slot 16] s_memtime stamps per workgroup, in the stamp buffer's region of this layer
 #define NRV_STAMP_W(slot)                                                                                    \
@@ -434,7 +431,7 @@ lstm_h2w_kernel(const LstmH2Args args) {
     // Group A's gate arithmetic of a step follows its rec() at once, in FRONT of barrier 1 - group A (the older waves, which
     // the SIMD's arbiter prefers) is through rec() 2.8 k cycles before group B (stamps, r04y) and would wait there; only the
     // 32 two-byte stores of h_s have to stay behind the barrier (other waves still read h_{s-1}).
-    constexpr bool DEFER = GRP_A && NRV_WS_DEFER;
+    constexpr bool DEFER = GRP_A;
     typedef std::integral_constant<bool, DEFER> defer_t;
     {
       stage_all(mk_stage(0));

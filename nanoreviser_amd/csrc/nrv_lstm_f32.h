@@ -29,25 +29,11 @@ struct LstmModelParams {
 // set, each keeping under 1 MB of weights resident.  Row blocks: 2*(b/8) + (g&1); a block past
 // n_blk exits.  Placement is a speed matter only.
 struct LstmBlock { int rowblk, dir, model; };
-#ifndef NRV_LSTM_MAP
-#define NRV_LSTM_MAP 0
-#endif
-#if NRV_LSTM_MAP == 0
 __device__ __forceinline__ LstmBlock lstm_block() {
   const int b = blockIdx.x, g = b & 7;
   return LstmBlock{((b >> 3) << 1) | (g & 1), (g >> 1) & 1, g >> 2};
 }
 __host__ __device__ constexpr int lstm_grid(int n_blk) { return 8 * ((n_blk + 1) / 2); }
-#else
-// Experiment (NRV_LSTM_MAP=1): the forward and the backward workgroup of a row block on the SAME XCD (blocks b and
-// b + 8), so that the input they both stream can meet in that XCD's L2; an XCD then holds both directions' weights of
-// one model (4 XCDs per model): row block 4 (b >> 4) + (g & 3), direction (b >> 3) & 1, model g >> 2.
-__device__ __forceinline__ LstmBlock lstm_block() {
-  const int b = blockIdx.x, g = b & 7;
-  return LstmBlock{((b >> 4) << 2) | (g & 3), (b >> 3) & 1, g >> 2};
-}
-__host__ __device__ constexpr int lstm_grid(int n_blk) { return 16 * ((n_blk + 3) / 4); }
-#endif
 
 struct LstmArgs {
   LstmModelParams m[2];

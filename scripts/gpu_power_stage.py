@@ -50,7 +50,7 @@ def sampler():
             samples.append((time.time(), float(p.group(1)), int(c.group(1))))
 
 
-names = {-1: "whole step", 0: "cnn_r_kernel (+ lstm1)", 2: "lstm2_t_kernel", 3: "lstm_h2w_kernel (192->128)",
+names = {-1: "whole step", 0: "cnn_r_kernel (+ lstm1)", 2: "lstm2_u_kernel", 3: "lstm_h2w_kernel (192->128)",
          4: "lstm_h2s_kernel (256->64)", 5: "head_h2_kernel"}
 res = {}
 for k in [int(x) for x in os.environ.get("POWER_STAGES", "-1,0,2,3,4,5").split(",")]:

@@ -12,7 +12,7 @@ N=${1:-1000}; SEED=${2:-1}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=$(mktemp -d "${TMPDIR:-/tmp}/nrv_sanitize.XXXXXX")
 trap 'rm -rf "$W"' EXIT
-FILES=$(ls "$ROOT"/tests/golden/fast5/*.fast5)
+FILES=$(ls "$ROOT"/tests/golden/fast5/*.fast5 "$ROOT"/tests/golden/fast5_more/*.fast5)
 CF="-O1 -g -fno-omit-frame-pointer -fno-fast-math -ffp-contract=off -pthread"
 gcc $CF -fsanitize=address,undefined -fno-sanitize-recover=all -o "$W/host_fuzz_asan" "$ROOT/tools/hostfuzz/host_fuzz.c" -lm -lz -ldl || exit 2
 export ASAN_OPTIONS=allocator_may_return_null=1:detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1

@@ -65,7 +65,6 @@ def test_helper_child_answers_json_commands_and_never_imports_torch():
 def test_kernel_signatures_are_what_the_library_launches():
     api = open(os.path.join(ROOT, "nanoreviser_amd", "csrc", "nrv_api.hip")).read()
     # 192 -> 128 layer, f16x2: launch_lstm_h2w<KQ0, KQ1, H> -> lstm_h2w_kernel<KQ0, KQ1, H, ACT, NRV_L3_WS_NBG>
-    assert re.search(r"#define NRV_L3_WS 1\b", api), "the 192->128 layer left lstm_h2w_kernel: update bench.KERNEL_SIGNATURE"
     m = re.search(r"launch_lstm_h2w<32, 16, 128>\(h, 2,", api)
     assert m, "the 192->128 launch of the f16x2 mode moved: update bench.KERNEL_SIGNATURE"
     nbg = re.search(r"#define NRV_L3_WS_NBG (\d+)", api).group(1)

@@ -82,10 +82,10 @@ def test_failure_contract_writes_original_bases(tmp_path):
     eng = EchoEngine(fail_marker=rt0.feat_ev[0])
     rc = cli.main(["-d", FAST5, "-o", out, "-S", "ecoli", "--thread", "1", "-e", "bad.txt"],
                   reviser_factory=lambda args, dev: eng)
-    assert rc == 0 and eng.calls == 3                                  # batch, retry read 0, retry read 1
+    assert rc == 0 and eng.calls == 1 + len(files)                     # the batch, then every read of it on its own
     failed = open(out + "bad.txt").read().split()
     assert failed == [files[0]]                                        # --failed_read is honoured
-    for fn in files:                                                   # both reads still produce a file
+    for fn in files:                                                   # every read still produces a file
         key = "_".join(fn.split("_")[-3:-1])
         _, rd, _ = load_read(key)
         orig = "".join(b.decode() for b in rd.bases.tolist())
@@ -177,9 +177,10 @@ def test_multi_gpu_worker_that_dies_does_not_hang_the_cli(tmp_path, factory):
 
 
 def test_resume_skips_reads_whose_output_exists(tmp_path):
-    """--resume (NanoReviser.py:196-201 removes the output directory and reruns everything; SURVEY.md 5: one file per
-    read makes skip-if-exists a free resume): finished reads are not touched, not even parsed; an EMPTY output is not a
-    finished one; a read the earlier run wrote unrevised stays in the failed-reads file."""
+    """--resume (the reference clears temp_dir and re-revises / overwrites every read, NanoReviser.py:196-201; SURVEY.md
+    5: one file per read makes skip-if-exists a free resume): finished reads are not touched, not even parsed; an EMPTY
+    output is not a finished one; a read the earlier run wrote UNREVISED (listed in its failed-reads file) is revised again
+    and replaced - or, with --resume_keep_failed, left alone, still listed, and the run returns 3."""
     import shutil
     src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
     d = tmp_path / "in"
@@ -193,17 +194,26 @@ def test_resume_skips_reads_whose_output_exists(tmp_path):
     open(out + "r2_out.fasta", "w").write("")                           # empty: not finished
     open(out + "r4_out.fasta", "w").write(">r4.fast5\nACGT")           # an earlier run's fallback output ...
     open(out + "failed_reads.txt", "w").write("r4.fast5\nr5.fast5\n")   # ... listed as failed; r5 has no output: redone
+    keep = EchoEngine()                                                  # --resume_keep_failed: r4 is left alone, exit code 3
+    assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1", "--resume", "--resume_keep_failed"],
+                    reviser_factory=lambda a, dev: keep) == 3
+    assert open(out + "r4_out.fasta").read() == ">r4.fast5\nACGT"
+    assert open(out + "failed_reads.txt").read().split() == ["r4.fast5", "broken.fast5"]
+    for i in (0, 2, 3, 5):
+        os.remove(out + f"r{i}_out.fasta")
+    open(out + "r2_out.fasta", "w").write("")
+    open(out + "failed_reads.txt", "w").write("r4.fast5\nr5.fast5\n")
     eng = EchoEngine()
     assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1", "--resume"], reviser_factory=lambda a, dev: eng) == 0
-    assert open(out + "r1_out.fasta").read() == "FINISHED EARLIER" and open(out + "r4_out.fasta").read() == ">r4.fast5\nACGT"
-    for i in (0, 2, 3, 5):
+    assert open(out + "r1_out.fasta").read() == "FINISHED EARLIER"
+    for i in (0, 2, 3, 4, 5):                                           # r4: the earlier run's fallback output is REPLACED
         assert open(out + f"r{i}_out.fasta").read() == f">r{i}.fast5\n" + _orig(os.path.basename(src[i % 2]))
-    assert open(out + "failed_reads.txt").read().split() == ["r4.fast5", "broken.fast5"]
+    assert open(out + "failed_reads.txt").read().split() == ["broken.fast5"]
     assert not [f for f in os.listdir(out) if ".tmp" in f]
     # a second --resume has nothing left but the unparsable file; without the flag everything is redone
     eng2 = EchoEngine()
     assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1", "--resume"], reviser_factory=lambda a, dev: eng2) == 0
-    assert eng2.calls == 0 and open(out + "failed_reads.txt").read().split() == ["r4.fast5", "broken.fast5"]
+    assert eng2.calls == 0 and open(out + "failed_reads.txt").read().split() == ["broken.fast5"]
     assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "1"], reviser_factory=lambda a, dev: EchoEngine()) == 0
     assert open(out + "r1_out.fasta").read() == ">r1.fast5\n" + _orig(os.path.basename(src[1]))
     assert open(out + "failed_reads.txt").read().split() == ["broken.fast5"]
@@ -506,3 +516,23 @@ def test_script_with_parser_pool_is_quiet_and_complete(tmp_path):
     for n in names:
         assert open(out + n + "_out.fasta").read() == ">" + n + ".fast5\n" + seq[n[-1]]
     assert open(out + "failed_reads.txt").read() == ""
+
+
+def test_output_directory_probe_warns_when_the_filesystem_is_too_slow(tmp_path, monkeypatch):
+    """VERDICT r05 next #10a: `NanoReviser.py --gpus 8` warns when the output directory cannot take the files eight GPUs
+    produce (r05: the sandbox's overlay root fed 68-78 M bases/s where tmpfs fed 120-131 M).  The probe leaves nothing
+    behind, runs only for multi-GPU runs with thousands of reads (or NRV_OUTPUT_PROBE=1), and can be turned off."""
+    out = str(tmp_path) + "/"
+    args = cli.get_args(["-d", out, "-o", out, "-S", "ecoli"])
+    rate = cli.probe_rename_rate(out, 200)
+    assert rate and rate > 0 and os.listdir(out) == []
+    msgs = []
+    assert cli.check_output_rate(args, 1, 10 ** 6, msgs.append) is None          # one GPU: no probe
+    assert cli.check_output_rate(args, 8, 100, msgs.append) is None              # a handful of reads: no probe
+    monkeypatch.setattr(cli, "probe_rename_rate", lambda d, pairs=2000: 900.0)
+    assert cli.check_output_rate(args, 8, 10 ** 5, msgs.append) == 900.0
+    assert len(msgs) == 1 and "900 file creations" in msgs[0] and "8 GPU workers" in msgs[0]
+    monkeypatch.setattr(cli, "probe_rename_rate", lambda d, pairs=2000: 1e6)
+    assert cli.check_output_rate(args, 8, 10 ** 5, msgs.append) == 1e6 and len(msgs) == 1
+    monkeypatch.setenv("NRV_OUTPUT_PROBE", "0")
+    assert cli.check_output_rate(args, 8, 10 ** 5, msgs.append) is None

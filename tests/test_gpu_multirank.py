@@ -44,6 +44,32 @@ def test_bench_n_ranks_share_one_device(n):
     print(f"MULTIRANK n={n}: {j['value']:.3e} bases/s, ms/step {j['ms_per_step']:.3f}, per rank {mm}")
 
 
+def test_two_ranks_sharing_the_device_deliver_the_one_rank_total():
+    """VERDICT r05 next #10c, a regression guard on the control plane: two ranks on ONE device share it, so the whole-job
+    `value` (units of all ranks / max-over-ranks time) must come out at about the one-rank value - a rank that is not
+    counted, or counted twice, or a barrier that lets one rank's clock run alone, shows up as a factor of two.  Also: every
+    rank's own ms_per_step sits next to its device identity, and the line carries its five timed blocks."""
+    def run(n):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5", "--prime", "200",
+               "--no-extras", "--no-cpu-baseline"] + (["--share-device"] if n > 1 else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = run(1), run(2)
+    ratio = two["value"] / one["value"]
+    assert 0.7 < ratio < 1.2, (one["value"], two["value"])
+    for j, n in ((one, 1), (two, 2)):
+        b = j["ms_per_step_blocks"]
+        assert len(b) == 5 and b[0] == pytest.approx(j["ms_per_step"], rel=1e-4)
+        lo, med, hi = j["ms_per_step_blocks_min_median_max"]
+        assert lo <= med <= hi and lo == pytest.approx(min(b), rel=1e-4) and hi == pytest.approx(max(b), rel=1e-4)
+        devs = j["config"]["devices"]
+        assert len(devs) == n and all(x["ms_per_step"] > 0 for x in devs)
+        assert max(x["ms_per_step"] for x in devs) <= j["ms_per_step"] * 1.0001
+    print(f"SHARE: 1 rank {one['value']:.3e}, 2 ranks on one device {two['value']:.3e} bases/s (x{ratio:.2f}); "
+          f"blocks {one['ms_per_step_blocks']}")
+
+
 def test_bench_refuses_more_ranks_than_devices_without_share_device():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--prime", "2", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,

@@ -4,7 +4,7 @@ The reference normalises samples as (raw - median) / MAD with no clipping (prepr
 the graph in f32 (nanorevcnn.py:24-37): a spike sample, an open-pore stretch or a tiny MAD has a well-defined
 answer.  The f32 and bf16x3 modes keep f32 buffers; the default f16x2 mode represents the signal branch as
 scaled f16 pairs (|S| < 1023) and must therefore DETECT what it cannot represent and hand back the f32
-kernels' result instead (include/nanorev.h nrv_saturated; nrv_cnn_f16x2.h "RANGE GUARD").  Checked here:
+kernels' result instead (include/nanorev.h nrv_saturated; nrv_cnn_r.h "Range guard").  Checked here:
 every mode against the fp64 oracle at 10x / 100x / 1000x the fixture amplitude, spikes inside otherwise clean
 reads (only the affected pipeline stage is re-run, and it is bit-identical to the f32 mode), int16 extremes with
 a tiny MAD through the raw-read entry point, NaN / Inf samples (propagated, not masked), and the

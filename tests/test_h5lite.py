@@ -33,8 +33,8 @@ def test_keras_weight_files(sp, m):
 
 
 def test_fast5_files_match_h5py_extraction():
-    files = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")))
-    assert len(files) == 2
+    files = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")) + glob.glob(os.path.join(GOLD, "fast5_more", "*.fast5")))
+    assert len(files) == 5                                   # all five of the reference's fixture reads (r06)
     for p in files:
         key = "_".join(os.path.basename(p).split("_")[-3:-1])
         g = np.load(os.path.join(GOLD, "reads", key + ".npz"))

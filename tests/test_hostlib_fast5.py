@@ -3,7 +3,7 @@ that defines it (h5lite + hoststage, themselves pinned to the reference's get_re
 fixture reads: tests/test_hoststage_golden.py).  CPU only.
 
   * nrvh_load_fast5 / nrvh_load_bundle: samples, event starts, features (bit pattern), bases, shift, scale and the Fastq
-    record of every fixture read - the two committed files and, in the build container, the reference's own five
+    record of every fixture read - the two committed files and the other three of the reference's own five (tests/golden/fast5_more)
   * whatever the native reader does not know is DECLINED (never guessed): a broken file, a truncated file at any length,
     a missing basecall group; the command line then runs the Python path and words the error as the reference does
   * nrvh_finish_read: merge + record + file, byte for byte cli._finish_in_worker's (hence the reference's writers') on
@@ -24,7 +24,7 @@ from nanoreviser_amd import hoststage as hs
 from echo_engine import EchoEngine, PackedEcho
 
 FAST5 = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")))
-REF5 = sorted(glob.glob("/root/reference/unitest/test_data/fast5/*.fast5"))     # build container only
+MORE5 = sorted(glob.glob(os.path.join(GOLD, "fast5_more", "*.fast5")))            # the other three of the reference's fixture reads (r06)
 G, SG = "Basecall_1D_000", "BaseCalled_template"
 
 pytestmark = pytest.mark.skipif(hostlib.load() is None, reason="libnanorev_host.so not built")
@@ -42,7 +42,7 @@ def _same(o, rt, fq):
             and o["fastq"] == fq)
 
 
-@pytest.mark.parametrize("path", FAST5 + [p for p in REF5 if os.path.basename(p) not in {os.path.basename(q) for q in FAST5}])
+@pytest.mark.parametrize("path", FAST5 + MORE5)
 def test_native_reader_gives_the_python_host_stage_bit_for_bit(path):
     rc, o = hostlib.load_fast5(path, G, SG, True)
     assert rc == hostlib.OK, o
@@ -142,7 +142,7 @@ def test_compound_datatype_from_the_file_is_checked_not_trusted(tmp_path):
 
 
 def test_byte_flip_fuzz_many_seeds_in_a_child_process(tmp_path):
-    """Random corruption of the metadata region and of whole-file positions, 60 seeds x 2 files: every outcome is a return
+    """Random corruption of the metadata region and of whole-file positions, 60 seeds x every fixture file: every outcome is a return
     code.  Run in a CHILD so that a crash of the native reader is this test's failure, not the end of the session."""
     import subprocess
     import sys
@@ -170,7 +170,7 @@ def test_byte_flip_fuzz_many_seeds_in_a_child_process(tmp_path):
         "print('fuzzed', n)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), FAST5, str(tmp_path / "f.fast5"), str(tmp_path / "f.fast5"), G, SG)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "fuzzed 120" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-2000:])
+    assert r.returncode == 0 and f"fuzzed {60 * len(FAST5)}" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-2000:])
 
 
 def test_two_reads_with_one_destination_never_share_a_temporary(tmp_path):

@@ -22,7 +22,7 @@ import pytest
 from conftest import GOLD
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAST5 = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")))
+FAST5 = sorted(glob.glob(os.path.join(GOLD, "fast5", "*.fast5")) + glob.glob(os.path.join(GOLD, "fast5_more", "*.fast5")))
 REPORTS = ("runtime error", "ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "WARNING: ThreadSanitizer", "SANITIZE FAIL")
 
 

@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ORD = 1: the three products of a chain as (hi*lo, hi*hi, lo*hi) - each operand changes ONCE per chain - instead of
 // (hi*lo, lo*hi, hi*hi)
 constexpr int kRec = 6;                                       // u64 per wave: c0, r0, c1, r1, HW_ID, XCC_ID
-template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1>
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1, int PPE = 12, int DEDUP = 0>
 __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, const float* __restrict__ xsrc, float* out, int steps,
                                                 unsigned long long* clk, const char* big = nullptr, char* bigw = nullptr) {
   __shared__ __attribute__((aligned(16))) float xl[6 * 4 * 2 * 256];             // 48 KB of "activations"
@@ -73,8 +73,19 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
         if (((e & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
       }
+      // DEDUP (SURVEY 7's second dedup, modelled): every fifth entry (2 of a step's 10 k-blocks: the signal branch's share of the
+      // 192 -> 128 input projection) is neither fetched nor multiplied; the wave loads 2 KB of precomputed accumulator-start values
+      // instead - the same bytes into the CU, a fifth fewer products.  1: from a 32 MB table (what one launch group's Z_sig
+      // would be: re-read, Infinity-Cache resident); 2: every address once (HBM)
+      if (DEDUP && e % 5 == 4) {
 #pragma unroll
-      for (int m = 0; m < 12; ++m) {
+        for (int t = 0; t < 2; ++t) {
+          acc[(e % 4) * 4 + t] = *(const f32x4*)(big + (DEDUP == 1 ? boff % ((size_t)32 << 20) : boff));
+          boff += 1024;
+        }
+      } else
+#pragma unroll
+      for (int m = 0; m < PPE; ++m) {                    // PPE = 6: a weight entry feeds two row tiles only (a 32-row wave)
         const int rt = ORD == 2 ? m % 4 : m / 3, pr = ORD == 2 ? m / 4 : m % 3;
         const f16x8 af = __builtin_bit_cast(f16x8, a[rt][ORD == 1 ? (pr == 2 ? 1 : 0) : (pr == 1 ? 1 : 0)]);
         const f16x8 bf = __builtin_bit_cast(f16x8, b[e % 4][pr == 0 ? 1 : 0]);
@@ -85,7 +96,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
           if (rt < 2) acc32[(e % 2) * 2 + rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc32[(e % 2) * 2 + rt], 0, 0, 0);
         } else
         acc[(e % 4) * 4 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[(e % 4) * 4 + rt], 0, 0, 0);
-        if (m < 2 && WEVERY > 0 && e % WEVERY == 0) {    // WEVERY = 2: a weight entry is fetched for every second entry only (the ring
+        if (m < 2 && WEVERY > 0 && e % WEVERY == 0 && !(DEDUP && en % 5 == 4)) {    // WEVERY = 2: a weight entry is fetched for every second entry only (the ring
           __builtin_amdgcn_sched_barrier(0);             // slot keeps its old bits otherwise); 0: no weight stream at all
           b[(e + 3) % 4][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (en * 2 + m) * 1024, 0));
           __builtin_amdgcn_sched_barrier(0);
@@ -123,12 +134,12 @@ static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return
 static double vmin(const std::vector<double>& v) { return *std::min_element(v.begin(), v.end()); }
 static double vmax(const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); }
 
-template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1>
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1, int PPE = 12, int DEDUP = 0>
 static void run(const char* name, const char* w, const float* x, float* out, unsigned long long* clk, int steps) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
-    hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD, PRIO, WEVERY>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+    hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD, PRIO, WEVERY, PPE, DEDUP>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
   };
   // SUSTAIN launches back to back first (argv[1], default 20 = a 3.5 ms burst; 12000 = two seconds of continuous load, after
   // which the clock is the one the chip HOLDS under this load), then the timed 20
@@ -160,7 +171,7 @@ static void run(const char* name, const char* w, const float* x, float* out, uns
   const int nw = 256 * 4 * WAVES;
   std::vector<unsigned long long> h((size_t)nw * kRec);
   hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
-  const double prod_per_wave = (double)steps * kEntries * 12;
+  const double prod_per_wave = (double)steps * kEntries * PPE * (DEDUP ? 0.8 : 1.0);   // products executed
   const double flop = 256.0 * 4 * WAVES * prod_per_wave * 16384.0 * (MF32 == 2 ? 1.0 : 1.0);
   unsigned long long first = ~0ull, last = 0;
   for (int i = 0; i < nw; ++i) { first = std::min(first, h[(size_t)i * kRec + 1]); last = std::max(last, h[(size_t)i * kRec + 3]); }
@@ -227,6 +238,8 @@ int main(int argc, char** argv) {
   hipMemcpy(w, hw.data(), wbytes, hipMemcpyHostToDevice); hipMemcpy(wz, hz.data(), wbytes, hipMemcpyHostToDevice);
   hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(xz, hxz.data(), hx.size() * 4, hipMemcpyHostToDevice);
   const int steps = 26;                                  // ~ two launches' worth of products per wave
+  hipMalloc(&g_big, (size_t)2048 * 1024 * 1024 + 4096); hipMalloc(&g_bigw, (size_t)2048 * 1024 * 1024 + (1 << 20));
+  hipMemset(g_big, 0, (size_t)2048 * 1024 * 1024);
   run<1, 0>("1 wave/SIMD, random operands", w, x, out, clk, steps);
   run<1, 0>("1 wave/SIMD, ZERO operands (same instructions)", wz, xz, out, clk, steps);
   run<1, 0, 0, 0, 2>("1 wave/SIMD, random, term-outer (independent neighbours)", w, x, out, clk, steps);
@@ -248,6 +261,13 @@ int main(int argc, char** argv) {
   run<2, 0, 0, 0, 0, 0, 0>("2 waves/SIMD, ZERO, NO weight stream", wz, xz, out, clk, steps);
   run<2, 0, 0, 0, 0, 2, 0>("2 waves/SIMD, random, NO weight stream, priority swapped", w, x, out, clk, steps);
   run<2, 0, 0, 0, 2, 0, 0>("2 waves/SIMD, random, NO weight stream, term-outer", w, x, out, clk, steps);
+  // a weight entry feeding 6 products instead of 12: what an eight-wave form of the 256->64 layer with 32-row waves would stream
+  run<2, 0, 0, 0, 0, 0, 1, 6>("2 waves/SIMD, random, 6 products per weight entry", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 0, 2, 1, 6>("2 waves/SIMD, random, 6 products per entry, priority swapped", w, x, out, clk, steps);
+  run<1, 0, 0, 0, 0, 0, 1, 6>("1 wave/SIMD, random, 6 products per weight entry", w, x, out, clk, steps);
+  // the second dedup, modelled on this loop: the wall time of a launch is the figure (the useful work is the same)
+  run<2, 0, 0, 0, 0, 0, 1, 12, 1>("2 waves/SIMD, random, DEDUP: 2 of 10 k-blocks as 2 KB loads from a 32 MB table", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 0, 0, 1, 12, 2>("2 waves/SIMD, random, DEDUP: ... every address once (HBM)", w, x, out, clk, steps);
   run<2, 1>("2 waves/SIMD, random, s_sleep 1 per entry", w, x, out, clk, steps);
   run<2, 2>("2 waves/SIMD, random, s_sleep 2 per entry", w, x, out, clk, steps);
   run<2, 4>("2 waves/SIMD, random, s_sleep 4 per entry", w, x, out, clk, steps);
@@ -255,8 +275,6 @@ int main(int argc, char** argv) {
   run<2, 4, 0, 0, 0, 2>("2 waves/SIMD, random, priority swapped, s_sleep 4", w, x, out, clk, steps);
   run<1, 2>("1 wave/SIMD, random, s_sleep 2 per entry", w, x, out, clk, steps);
   run<1, 4>("1 wave/SIMD, random, s_sleep 4 per entry", w, x, out, clk, steps);
-  hipMalloc(&g_big, (size_t)2048 * 1024 * 1024 + 4096); hipMalloc(&g_bigw, (size_t)2048 * 1024 * 1024 + (1 << 20));
-  hipMemset(g_big, 1, (size_t)2048 * 1024 * 1024);
   run<2, 0, 1>("2 waves/SIMD, random + HBM stream (1 KB / 6 entries, store / 8)", w, x, out, clk, steps);
   run<2, 0, 1, 0, 0, 2>("2 waves/SIMD, random + HBM stream, priority swapped", w, x, out, clk, steps);
   run<1, 0, 1>("1 wave/SIMD, random + HBM stream", w, x, out, clk, steps);
