@@ -3,6 +3,7 @@
 #include "../../include/nanorev.h"
 #include "nrv_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1595,8 +1596,20 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   const bool direct_s = !raw_reads && pin_s.pin(h, sig, ev_all * kSig * 4);
   const bool direct_f = pin_f.pin(h, feat, ev_all * kFeat * 4);
   const double ms_reg = since(t_0);
-  // a pipeline stage = one upload, its launch groups (on the lanes when groups are small), one download
-  const int stage = stage_windows(h, read_mode);
+  // a pipeline stage = one upload, its launch groups (on the lanes when groups are small), one download.
+  // WINDOW mode (2958 B per base over PCIe) ramps its stages: 1, 1, 2, then kWinStageMax launch groups - the first upload, which
+  // nothing can hide, stays one group (12 MB, 0.22 ms), and the later stages pay the cross-stream hand-over (~10-15 us) once per
+  // 2-4 groups instead of once per group (r06; NRV_WINDOW_STAGE_MAX=1: one group per stage as before).  Read modes: constant.
+  static const int kWinStageMax = [] { const char* e = getenv("NRV_WINDOW_STAGE_MAX"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  const int stage0 = stage_windows(h, read_mode);
+  const bool ramp = !read_mode && lanes_wanted(h) <= 1 && kWinStageMax > 1;
+  const int max_groups = ramp ? std::min(kWinStageMax, std::max(1, h->cap_rows / stage0)) : 1;
+  const int stage = stage0 * max_groups;                       // the largest stage: staging capacity
+  auto stage_size = [&](int64_t k) -> int {                  // windows of stage k
+    if (!ramp) return stage0;
+    const int g = k < 2 ? 1 : (k == 2 ? 2 : max_groups);
+    return stage0 * (g < max_groups ? g : max_groups);
+  };
   const size_t ev_grp = read_mode ? (size_t)(stage + T - 1) : (size_t)stage * T;
   if (!raw_reads && !direct_s && (rc = grow_pinned(h, h->pin_sig, &h->pin_sig_cap, ev_grp * kSig * 4))) return rc;
   if (!direct_f && (rc = grow_pinned(h, h->pin_feat, &h->pin_feat_cap, ev_grp * kFeat * 4))) return rc;
@@ -1642,8 +1655,8 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   // with upload_raw and the windows are cut on the device).  ONE copy per array: two halves on two copy streams were measured
   // (r05c: 3.40 vs 3.30 ms per 8-stage call) - a single stream already moves 53-57 GB/s whichever way the memory was
   // page-locked (tools/microbench/h2d_rate.hip).
-  auto upload = [&](int64_t s, int si) -> int {
-    const int nb = (int)((n - s < stage) ? (n - s) : stage);
+  auto upload = [&](int64_t s, int si, int want) -> int {
+    const int nb = (int)((n - s < want) ? (n - s) : want);
     const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
     if (!raw_reads) {
       const float* hs = sig + (read_mode ? s * kSig : s * T * kSig);
@@ -1663,17 +1676,18 @@ static int predict_host(nrv_handle* h, const float* sig, const float* feat, int6
   // NRV_HOST_TRACE=2: timing events around every stage's kernels (span of the kernels, gap to the previous stage's)
   static const bool trace2 = getenv("NRV_HOST_TRACE") && atoi(getenv("NRV_HOST_TRACE")) > 1;
   std::vector<hipEvent_t> tev;
-  if ((rc = upload(0, 0))) return rc;
-  for (int64_t s = 0; s < n; s += stage, ++g) {
+  if ((rc = upload(0, 0, stage_size(0)))) return rc;
+  for (int64_t s = 0; s < n; s += stage_size(g), ++g) {
     const int si = (int)(g % nrv_handle::kIn), st = (int)(g & 1);
-    const int nb = (int)((n - s < stage) ? (n - s) : stage);
+    const int cur = stage_size(g);
+    const int nb = (int)((n - s < cur) ? (n - s) : cur);
     const size_t ev = read_mode ? (size_t)(nb + T - 1) : (size_t)nb * T;
     // Stage g+1's upload goes out FIRST, into the input set stage g-2 used.  Nothing has to be waited for: the previous
     // iteration ended with finalize(g-2) - a HOST wait for that stage's download (ev_out), which ran behind its kernels
     // (ev_done), which ran behind its upload (ev_in) - so that set's bounce buffers and d_sig / d_feat are free, and so are
     // the output set d_p / d_a of stage g-2 that this stage's kernels write.  (Until r05 three waits stood here, one of them
     // a barrier packet on the compute stream per stage.)
-    if (s + stage < n && (rc = upload(s + stage, (int)((g + 1) % nrv_handle::kIn)))) return rc;
+    if (s + cur < n && (rc = upload(s + cur, (int)((g + 1) % nrv_handle::kIn), stage_size(g + 1)))) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[si], 0));
     if (trace2 && tev.size() < 128) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); HIPCHK(h, hipEventRecord(e, h->stream)); tev.push_back(e); }
     if (raw_reads) launch_segment(h, raw_reads, s, (int)ev, h->d_sig[si]);

@@ -1,6 +1,6 @@
 """The host-pointer pipeline of nrv_predict over MANY stages (MI355X only, -m gpu): three input staging sets in rotation, two
 output sets, uploads one stage ahead, one download per stage (csrc/nrv_api.hip predict_host, r05).  Results do not depend on
-the grouping, so a call of seven stages must give, window for window, the bits of one-stage calls on the same windows -
+the grouping, so a call of many stages (ramped: 1, 1, 2, 4, 4 ... launch groups, r06) must give, window for window, the bits of one-stage calls on the same windows -
 with the caller's arrays registered in place AND through the bounce buffers (NRV_HOST_REGISTER=0) - and a stage that trips
 the f16x2 range guard late in the call (its inputs must still be in their staging set) must come back with the f32 kernels'
 bits while its neighbours keep theirs."""
@@ -14,10 +14,23 @@ from nanoreviser_amd import hoststage as hs
 pytestmark = pytest.mark.gpu
 
 
+def _stages(n, group=4096):
+    """The window-mode stage schedule of predict_host (r06): 1, 1, 2, then NRV_WINDOW_STAGE_MAX (default 4) launch groups per
+    stage -> [(lo, hi)] in windows.  (The variable is read once per process by the library: set it for the whole test run.)"""
+    mx = max(1, min(8, int(os.environ.get("NRV_WINDOW_STAGE_MAX", "4"))))
+    out, s, k = [], 0, 0
+    while s < n:
+        g = 1 if (k < 2 or mx == 1) else (2 if k == 2 else mx)
+        g = min(g, mx)
+        out.append((s, min(s + g * group, n)))
+        s, k = out[-1][1], k + 1
+    return out
+
+
 def _seven_stages(reads, T=11):
     _, _, rt = reads("ch13_read2251")
     sw, fw = hs.sliding_windows(rt.sig_ev, rt.feat_ev, T)
-    n = 6 * 4096 + 1234                                            # seven stages, the last one ragged
+    n = 13 * 4096 + 1234                                           # fourteen launch groups, the last one ragged: six stages (1, 1, 2, 4, 4, 2)
     idx = np.arange(n) % (len(fw) - 7)                             # the read's windows, wrapped around
     idx = (idx * 7919) % (len(fw) - 7)                             # ... and shuffled: every stage holds different windows
     return np.ascontiguousarray(sw[idx]), np.ascontiguousarray(fw[idx])
@@ -31,7 +44,7 @@ def test_seven_stage_call_equals_one_stage_calls(reads, species_models, register
     sw, fw = _seven_stages(reads)
     rv = Reviser(m1, m2, precision="f16x2")
     whole = rv.predict_pair(sw, fw)
-    for s in (0, 3, 5, 6):                                         # stages 0, 3 (first reuse of input set 0), 5, the ragged last
+    for s in (0, 3, 5, 9, 13):                                     # launch groups in stages 0, 2, 3 (first reuse of input set 0), 4, the ragged last
         lo, hi = s * 4096, min((s + 1) * 4096, len(fw))
         part = rv.predict_pair(np.ascontiguousarray(sw[lo:hi]), np.ascontiguousarray(fw[lo:hi]))
         for w, p in zip(whole, part):
@@ -48,7 +61,7 @@ def test_late_stage_range_rerun_keeps_its_inputs(reads, species_models):
     sw, fw = _seven_stages(reads)
     clean = sw.copy()
     rng = np.random.default_rng(11)
-    for stage in (4, 6):                                           # spikes in stage 4 (input set 1, second use) and in the last
+    for stage in (4, 13):                                          # spikes in launch group 4 (stage 3) and in the last one
         lo = stage * 4096
         for w in lo + rng.choice(min(4096, len(fw) - lo), 25, replace=False):
             sw[w, rng.integers(11), rng.integers(50)] *= np.float32(2000.0)
@@ -56,15 +69,18 @@ def test_late_stage_range_rerun_keeps_its_inputs(reads, species_models):
     base = rv.predict_pair(clean, fw)
     assert rv.saturated() == (0, 0)
     got = rv.predict_pair(sw, fw)
-    assert rv.saturated() == (0, 2)                                # exactly the two spiked stages were re-run
+    # a STAGE is re-run whole (with the ramped schedule a stage is up to four launch groups)
+    st = _stages(len(fw))
+    hit = [i for i, (lo, hi) in enumerate(st) if any(lo <= g * 4096 < hi for g in (4, 13))]
+    assert len(hit) == 2
+    assert rv.saturated() == (0, len(hit))                         # exactly the spiked stages were re-run
     rv.set_precision("f32")
     ref32 = rv.predict_pair(sw, fw)
     rv.close()
     for g, b, r in zip(got, base, ref32):
-        for stage in range(7):
-            lo, hi = stage * 4096, min((stage + 1) * 4096, len(fw))
-            want = r if stage in (4, 6) else b
-            assert np.array_equal(g[lo:hi].view(np.uint8), want[lo:hi].view(np.uint8)), stage
+        for i, (lo, hi) in enumerate(st):
+            want = r if i in hit else b
+            assert np.array_equal(g[lo:hi].view(np.uint8), want[lo:hi].view(np.uint8)), (i, lo, hi)
 
 
 def test_raw_read_call_of_five_stages_equals_shorter_calls(species_models):

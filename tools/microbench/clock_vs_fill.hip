@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ORD = 1: the three products of a chain as (hi*lo, hi*hi, lo*hi) - each operand changes ONCE per chain - instead of
 // (hi*lo, lo*hi, hi*hi)
 constexpr int kRec = 6;                                       // u64 per wave: c0, r0, c1, r1, HW_ID, XCC_ID
-template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1, int PPE = 12, int DEDUP = 0>
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1, int PPE = 12, int DEDUP = 0, int NB = 4, int LOADER = 0>
 __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, const float* __restrict__ xsrc, float* out, int steps,
                                                 unsigned long long* clk, const char* big = nullptr, char* bigw = nullptr) {
   __shared__ __attribute__((aligned(16))) float xl[6 * 4 * 2 * 256];             // 48 KB of "activations"
@@ -51,14 +51,41 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
   f32x16 acc32[4];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
-  f32x4 b[4][2], a[4][2];
-  for (int e = 0; e < (WEVERY == 1 ? 3 : 4); ++e)
+  static_assert(kEntries % NB == 0, "ring");
+  f32x4 b[NB][2], a[4][2];                               // NB: weight ring entries (NB - 1 in flight per wave: 2 KB each)
+  for (int e = 0; e < (WEVERY == 1 ? NB - 1 : NB); ++e)
     for (int t = 0; t < 2; ++t) b[e][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (e * 2 + t) * 1024, 0));
   f32x4 hb = f32x4{0.f, 0.f, 0.f, 0.f};
   size_t boff = ((size_t)(blockIdx.x * 4 * WAVES + wave) * 1024) * 1024 + lane * 16;   // 1 MB per wave and launch
   unsigned long long c0, r0, c1, r1;
+  float sink0 = 0.f;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
   if (PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // LOADER (two waves per SIMD): waves 4-7 do NOTHING but issue the weight stream of one consumer wave each (2 KB per entry, at
+  // most 8 KB in flight; 1: into registers, 2: by LDS-DMA into a 4 KB ring of their own), waves 0-3 multiply without any
+  // vector-memory instruction (run with WEVERY = 0).  Does a 1 KB request cost the ISSUING wave its time, or the SIMD?
+  if (LOADER && wave >= 4) {
+    f32x4 sinkv = f32x4{0.f, 0.f, 0.f, 0.f};
+    __shared__ __attribute__((aligned(16))) float ring[4 * 4 * 256];
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll 8
+      for (int e = 0; e < kEntries; ++e) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if constexpr (LOADER == 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ring + ((wave - 4) * 4 + (e & 1) * 2 + t) * 256), 16, lane * 16,
+                                                 (e * 2 + t) * 1024, 0, 0);
+          } else {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (e * 2 + t) * 1024, 0));
+            asm volatile("" ::"v"(v));
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sink0 = sinkv[0];
+  } else
   for (int s = 0; s < steps; ++s) {
 #pragma unroll
     for (int e = 0; e < kEntries; ++e) {
@@ -68,7 +95,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
 #pragma unroll
           for (int t = 0; t < 2; ++t) a[rt][t] = *(const f32x4*)(xl + ((((e / 4) % 6) * 4 + rt) * 2 + t) * 256 + lane * 4);
       }
-      const int en = (e + 3) % kEntries;
+      const int en = (e + NB - 1) % kEntries;
       if (PRIO == 2) {
         if (((e & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
@@ -80,7 +107,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
       if (DEDUP && e % 5 == 4) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          acc[(e % 4) * 4 + t] = *(const f32x4*)(big + (DEDUP == 1 ? boff % ((size_t)32 << 20) : boff));
+          acc[(e % 4) * 4 + t] += *(const f32x4*)(big + (DEDUP == 1 ? boff % ((size_t)32 << 20) : boff));   // (+=: an overwrite would make the products in front of it dead code)
           boff += 1024;
         }
       } else
@@ -88,7 +115,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
       for (int m = 0; m < PPE; ++m) {                    // PPE = 6: a weight entry feeds two row tiles only (a 32-row wave)
         const int rt = ORD == 2 ? m % 4 : m / 3, pr = ORD == 2 ? m / 4 : m % 3;
         const f16x8 af = __builtin_bit_cast(f16x8, a[rt][ORD == 1 ? (pr == 2 ? 1 : 0) : (pr == 1 ? 1 : 0)]);
-        const f16x8 bf = __builtin_bit_cast(f16x8, b[e % 4][pr == 0 ? 1 : 0]);
+        const f16x8 bf = __builtin_bit_cast(f16x8, b[e % NB][pr == 0 ? 1 : 0]);
         if constexpr (MF32 == 2) {                       // v_mfma_i32_16x16x64_i8: twice the MACs per instruction, same operand bytes
           acci[(e % 4) * 4 + rt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af), __builtin_bit_cast(i32x4, bf),
                                                                           acci[(e % 4) * 4 + rt], 0, 0, 0);
@@ -98,7 +125,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
         acc[(e % 4) * 4 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[(e % 4) * 4 + rt], 0, 0, 0);
         if (m < 2 && WEVERY > 0 && e % WEVERY == 0 && !(DEDUP && en % 5 == 4)) {    // WEVERY = 2: a weight entry is fetched for every second entry only (the ring
           __builtin_amdgcn_sched_barrier(0);             // slot keeps its old bits otherwise); 0: no weight stream at all
-          b[(e + 3) % 4][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (en * 2 + m) * 1024, 0));
+          b[(e + NB - 1) % NB][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (en * 2 + m) * 1024, 0));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -113,7 +140,7 @@ __global__ void __launch_bounds__(256 * WAVES) k(const char* __restrict__ w, con
     }
   }
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
-  float sink = 0.f;
+  float sink = sink0;
   for (int i = 0; i < 16; ++i) sink += acc[i][0] + acc[i][3];
   for (int i = 0; i < 4; ++i) sink += acc32[i][0] + acc32[i][15];
   for (int i = 0; i < 16; ++i) sink += (float)(acci[i][0] + acci[i][3]);
@@ -134,12 +161,12 @@ static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return
 static double vmin(const std::vector<double>& v) { return *std::min_element(v.begin(), v.end()); }
 static double vmax(const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); }
 
-template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1, int PPE = 12, int DEDUP = 0>
+template <int WAVES, int SLEEP, int STREAM = 0, int MF32 = 0, int ORD = 0, int PRIO = 0, int WEVERY = 1, int PPE = 12, int DEDUP = 0, int NB = 4, int LOADER = 0>
 static void run(const char* name, const char* w, const float* x, float* out, unsigned long long* clk, int steps) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
-    hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD, PRIO, WEVERY, PPE, DEDUP>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
+    hipLaunchKernelGGL((k<WAVES, SLEEP, STREAM, MF32, ORD, PRIO, WEVERY, PPE, DEDUP, NB, LOADER>), dim3(256), dim3(256 * WAVES), 0, 0, w, x, out, steps, clk, g_big, g_bigw);
   };
   // SUSTAIN launches back to back first (argv[1], default 20 = a 3.5 ms burst; 12000 = two seconds of continuous load, after
   // which the clock is the one the chip HOLDS under this load), then the timed 20
@@ -265,6 +292,14 @@ int main(int argc, char** argv) {
   run<2, 0, 0, 0, 0, 0, 1, 6>("2 waves/SIMD, random, 6 products per weight entry", w, x, out, clk, steps);
   run<2, 0, 0, 0, 0, 2, 1, 6>("2 waves/SIMD, random, 6 products per entry, priority swapped", w, x, out, clk, steps);
   run<1, 0, 0, 0, 0, 0, 1, 6>("1 wave/SIMD, random, 6 products per weight entry", w, x, out, clk, steps);
+  // memory-level parallelism: the weight ring deeper (8 entries: 7 x 2 KB in flight per wave instead of 3)
+  run<2, 0, 0, 0, 0, 0, 1, 12, 0, 8>("2 waves/SIMD, random, weight ring of 8 entries", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 0, 2, 1, 12, 0, 8>("2 waves/SIMD, random, ring of 8, priority swapped", w, x, out, clk, steps);
+  run<1, 0, 0, 0, 0, 0, 1, 12, 0, 8>("1 wave/SIMD, random, weight ring of 8 entries", w, x, out, clk, steps);
+  run<1, 0, 0, 0, 0, 0, 1, 12, 0, 20>("1 wave/SIMD, random, weight ring of 20 entries", w, x, out, clk, steps);
+  // who pays for a vector-memory instruction: loader waves beside consumer waves
+  run<2, 0, 0, 0, 0, 0, 0, 12, 0, 4, 1>("2 waves/SIMD: waves 0-3 multiply (no weight stream), waves 4-7 only LOAD it (registers)", w, x, out, clk, steps);
+  run<2, 0, 0, 0, 0, 0, 0, 12, 0, 4, 2>("2 waves/SIMD: waves 0-3 multiply (no weight stream), waves 4-7 only LOAD it (LDS-DMA)", w, x, out, clk, steps);
   // the second dedup, modelled on this loop: the wall time of a launch is the figure (the useful work is the same)
   run<2, 0, 0, 0, 0, 0, 1, 12, 1>("2 waves/SIMD, random, DEDUP: 2 of 10 k-blocks as 2 KB loads from a 32 MB table", w, x, out, clk, steps);
   run<2, 0, 0, 0, 0, 0, 1, 12, 2>("2 waves/SIMD, random, DEDUP: ... every address once (HBM)", w, x, out, clk, steps);
