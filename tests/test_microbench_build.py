@@ -1,6 +1,6 @@
 """The microbenchmarks the design argues from (tools/microbench/*.hip) must keep compiling for gfx950: hipcc cross-compiles
-without a GPU.  They are run on the GPU box by hand (their headers say how); their recorded outputs are profiles/r04_tick_cost.txt
-and profiles/r04_clock_vs_fill.txt."""
+without a GPU.  They are run on the GPU box by hand (their headers say how); their recorded outputs are profiles/r04_tick_cost.txt,
+profiles/r04_clock_vs_fill.txt and - every wave stamped, which corrected r04's reading - profiles/r06_clock_vs_fill.txt."""
 import glob
 import os
 import shutil
