@@ -1141,6 +1141,13 @@ def cli_e2e(reps, threads, gpus=1, share=False, species="ecoli", all_five=False,
 
 
 # ------------------------------------------------------------------------------------------------
+def device_key(x):
+    """What makes two ranks' devices the same device: PCI address + UUID; when a runtime reports neither (all zeros / empty)
+    the device INDEX stands in, so that an uninformative identity can never make a real N-GPU run look like one device."""
+    informative = x.get("pci") not in (None, "", "0000:00:00") or str(x.get("uuid")) not in ("", "None")
+    return (x.get("pci"), str(x.get("uuid"))) if informative else ("index", x.get("device"))
+
+
 def check_world(args):
     """Before any rendezvous: a launcher's WORLD_SIZE and --gpus must agree."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1203,7 +1210,7 @@ def run_rank(args):
              "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
              "uuid": str(getattr(pr, "uuid", ""))}
     devices = d.gather_obj(ident)
-    n_distinct = len({(x["pci"], x["uuid"]) for x in devices})
+    n_distinct = len({device_key(x) for x in devices})
     if n_distinct < d.world and not args.share_device:
         # an N-GPU line that ran on fewer than N devices is not an N-GPU measurement (the data path has no collective that
         # would notice): refuse, loudly, before anything is timed (every rank sees the same gathered list and leaves)
@@ -1282,7 +1289,7 @@ def run_rank(args):
             "parallelism": f"read/window-sharded x{args.gpus}, no collectives; control plane on gloo (CPU tensors)"
                            + (f"; --share-device: {d.world} ranks on {ndev} device(s)" if args.share_device else ""),
             "world_size": d.world, "devices": devices,
-            "distinct_devices": len({(x["pci"], x["uuid"]) for x in devices}),
+            "distinct_devices": len({device_key(x) for x in devices}),
             "parity_guard_max_abs_dp": dp,
             "prime_note": f"{args.prime} untimed priming steps, then untimed blocks of 200 steps until three in a row agree "
                           f"within 1 % (<= 40 blocks), precede the {args.warmup} warm-up steps (clock settling)",

@@ -31,6 +31,15 @@
 //     wave, h_t goes through an LDS image (lstm_h2s_kernel: double-buffered, one barrier per step; lstm_h2w_kernel:
 //     one image, two barriers; lstm2_u_kernel: the two halves of a chain's h_t through LDS, one barrier)
 //     and is written out coalesced, the BatchNorm behind it fused or folded into the next layer's weights.
+//
+// Compile-time switches left in these sources (round 6 removed the experiment variants that lost; HISTORY.md keeps the record).
+// None of them selects another product kernel; all are 0 / undefined in the product build (__graft_entry__.build_hip):
+//   NRV_STAMP (+ NRV_STAMP_REC_ENTRIES)   DIAGNOSTIC ONLY: s_memtime stamps at the phase edges of lstm_h2s_kernel / lstm_h2w_kernel and
+//                                         nrv_exp_only_stage / nrv_exp_stamps (scripts/gpu_stamps*.py, gpu_power_stage.py)
+//   NRV_DEV_FAST (-> NRV_ACT1)            DEVELOPMENT ONLY: f16x2 mode with hard_sigmoid only, half the compile time (tools/lstm_exp.sh)
+//   NRV_L3_WS_NBG                         the 192->128 layer's weight ring (4; 8 spills: r04w) - bench.KERNEL_SIGNATURE follows it
+// Run-time environment variables of the engine: NRV_COALESCE / NRV_LANES (round 3's stream lanes instead of coalesced 4096-window
+// groups: tests/test_gpu_parity.py grouping tests), NRV_READ_STAGE, NRV_WINDOW_STAGE_MAX, NRV_HOST_REGISTER, NRV_HOST_TRACE.
 #pragma once
 #include "nrv_common.h"        // vector types, buffer loads, activations, ActView
 #include "nrv_cnn.h"           // cnn_kernel
