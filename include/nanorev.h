@@ -88,6 +88,19 @@ typedef struct {
 int nrv_predict_reads_raw(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts,
                           const float* feat_ev, int64_t N, const nrv_read_desc* reads, int n_reads,
                           float* p1, float* p2, int8_t* a1, int8_t* a2);
+/* The same call in two halves (r06), so that a caller can have the device work on call k+1 while it collects call k - what the
+ * reference's per-read Pool tasks (NanoReviser.py:203-219) get from running several `predict` calls side by side:
+ *   nrv_reads_raw_begin  copies the inputs (92 B per base) into page-locked staging - they may be freed or reused as soon as it
+ *                        returns -, uploads them in one transfer and enqueues EVERY stage of the call; *ticket names the call;
+ *   nrv_reads_raw_end    waits for that call's results and writes them to the p1 / p2 / a1 / a2 given to _begin (which must stay
+ *                        valid until then; any may be NULL).  A call that tripped the f16x2 range guard is re-run whole on the
+ *                        f32 kernels here (nrv_saturated's *reruns counts it).
+ * At most two calls in flight per handle (a third _begin returns NRV_E_INVALID); calls complete in the order they began; between
+ * a _begin and its _end only these two entry points may be called on the handle.  nrv_predict_reads_raw IS _begin + _end. */
+int nrv_reads_raw_begin(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts,
+                        const float* feat_ev, int64_t N, const nrv_read_desc* reads, int n_reads,
+                        float* p1, float* p2, int8_t* a1, int8_t* a2, int* ticket);
+int nrv_reads_raw_end(nrv_handle* h, int ticket);
 /* The segmentation alone: sig_ev [N][50] f32 to HOST memory (what nrv_predict_reads_raw feeds the
  * signal branch; bit-identical to the host stage - used by the parity tests). */
 int nrv_segment_reads(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts, int64_t N,

@@ -644,6 +644,54 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
         finally:
             free.put(reviser)
 
+    # Device calls PIPELINED two deep (r06; one engine, native bundles; NRV_CLI_PIPELINE=0: one call at a time as before): the
+    # engine thread enqueues bundle k+1 (nrv_reads_raw_begin: inputs copied, every stage enqueued) BEFORE it collects bundle k
+    # (nrv_reads_raw_end), so the device never waits for a call's fill, drain or the Python between two calls.
+    pipelined = n_eng == 1 and os.environ.get("NRV_CLI_PIPELINE", "1") != "0"
+    pending = {}                                      # id(engine) -> the call in flight on it: (ticket, batch, bundle, trace index, t0)
+
+    def _done():
+        from concurrent.futures import Future
+        f = Future()
+        f.set_result(None)
+        return f
+
+    def collect(reviser, item):
+        """Second half of a pipelined call: wait for it, hand its reads to the finisher; a failure is isolated read by read
+        on the synchronous path, exactly as for an unpipelined call."""
+        tk, batch, bundle, ti, t_begin = item
+        t0 = time.perf_counter()
+        try:
+            outs = reviser.end_packed_raw(tk)
+        except Exception:
+            # the per-read retries are other entry points of the handle: first collect the call that was enqueued behind this one
+            nxt = pending.pop(id(reviser), None)
+            if nxt is not None:
+                collect(reviser, nxt)
+            calls = []
+            for rt in _bundle_reads(bundle):
+                try:
+                    calls.append(predict_one(reviser, rt))
+                except Exception as e:
+                    calls.append(e)
+            with stats_lock:
+                stats["engine_s"] += time.perf_counter() - t0
+            return fin.submit(finish_batch, batch, calls)         # (the finisher is one thread: behind nxt's hand-over)
+        with stats_lock:
+            stats["engine_s"] += time.perf_counter() - t0
+        if ti is not None:
+            trace[ti] = ("call", t_begin - t_start, time.perf_counter() - t_begin)
+        return fin.submit(finish_bundle, batch, bundle, outs)
+
+    def flush_pipeline():
+        """Engine thread, behind the last batch: whatever is still in flight."""
+        last = _done()
+        for rv in list(engines):
+            item = pending.pop(id(rv), None)
+            if item is not None:
+                last = collect(rv, item)
+        return last
+
     def run_batch_on(reviser, batch, packed, bundle):
         t0 = time.perf_counter()
         ti = None
@@ -651,6 +699,21 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             ti = len(trace)
             trace.append(("call", t0 - t_start, 0.0))
         rts = None
+        prev = pending.pop(id(reviser), None)
+        if (pipelined and bundle is not None and packed is not None and native_threads and pool is not None
+                and hasattr(reviser, "begin_packed_raw") and "bases" in bundle
+                and len(bundle["bases"]) == int(bundle["meta"][:, 1].sum())):
+            try:
+                tk = reviser.begin_packed_raw(packed)
+            except Exception:
+                tk = None                             # e.g. a handle that could not grow its buffers: the synchronous path decides
+            if tk is not None:
+                pending[id(reviser)] = (tk, batch, bundle, ti, t0)
+                with stats_lock:
+                    stats["engine_s"] += time.perf_counter() - t0
+                return collect(reviser, prev) if prev is not None else _done()
+        if prev is not None:                          # between a call's two halves nothing else may run on its handle
+            collect(reviser, prev)
 
         def reads():                                  # the reads as tensors: only the per-read paths need them
             return _bundle_reads(bundle) if bundle is not None else [rt for _, rt, _ in batch]
@@ -771,6 +834,8 @@ def process_files(args, files: Sequence[str], reviser, log: Callable[[str], None
             collect_finished(False)
         if batch:
             inflight.append(submit(batch))
+        if pipelined:
+            inflight.append(eng.submit(flush_pipeline))
         drain(0)
         if created is not None:
             created.result()

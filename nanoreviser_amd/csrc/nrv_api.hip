@@ -526,6 +526,21 @@ struct nrv_handle {
   SegRead* d_reads = nullptr;
   size_t cap_raw = 0, cap_starts = 0, cap_reads = 0;
   hipEvent_t ev_raw = nullptr;
+  // Whole-call raw-read calls (nrv_reads_raw_begin / _end, r06): a call's inputs are 92 B per base, so ALL of them go up in one
+  // copy and ALL its stages are enqueued on the compute stream in one go - no per-stage hand-over between streams - and its
+  // results come back in one block.  Two slots, so that a caller can enqueue call k+1 before it collects call k.
+  struct RawSlot {
+    char* d_in = nullptr; char* pin_in = nullptr; size_t cap_in = 0;     // [raw i16 | starts i32 | reads | feat f32], 256-B aligned parts
+    char* d_out = nullptr; char* pin_out = nullptr; size_t cap_out = 0;   // [counter 64 B | p1 | p2 | a1 | a2]
+    size_t off_starts = 0, off_reads = 0, off_feat = 0, rows = 0;
+    int64_t N = 0, n = 0;
+    int n_reads = 0;
+    float *p1 = nullptr, *p2 = nullptr;
+    int8_t *a1 = nullptr, *a2 = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+    unsigned sat_seen = 0;
+    bool busy = false;
+  } raw_slot[2];
   // f16x2 range guard (cnn_h2_kernel): device counters [0], [1] = the staging sets of the host-pointer entry
   // points (downloaded with each stage's outputs), [2] = device-pointer calls (read by nrv_saturated)
   unsigned* d_sat = nullptr;
@@ -1344,6 +1359,12 @@ void nrv_destroy(nrv_handle* h) {
     if (h->ev_out[st]) (void)hipEventDestroy(h->ev_out[st]);
   }
   (void)hipFree(h->d_raw); (void)hipFree(h->d_starts); (void)hipFree(h->d_reads);
+  for (auto& sl : h->raw_slot) {
+    (void)hipFree(sl.d_in); (void)hipFree(sl.d_out); (void)hipHostFree(sl.pin_in); (void)hipHostFree(sl.pin_out);
+    if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+    if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+  }
   (void)hipFree(h->d_sat);
   if (h->ev_raw) (void)hipEventDestroy(h->ev_raw);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1510,9 +1531,11 @@ static int upload_raw(nrv_handle* h, const int16_t* raw, int64_t n_raw, const in
   return NRV_OK;
 }
 
-static void launch_segment(nrv_handle* h, int n_reads, int64_t ev0, int n_ev, float* d_out) {
+static void launch_segment(nrv_handle* h, int n_reads, int64_t ev0, int n_ev, float* d_out, const int16_t* d_raw = nullptr,
+                           const int32_t* d_starts = nullptr, const SegRead* d_reads = nullptr) {
   if (n_ev <= 0) return;
-  SegArgs a{(const short*)h->d_raw, (const int*)h->d_starts, h->d_reads, n_reads, (long long)ev0, n_ev, d_out};
+  SegArgs a{(const short*)(d_raw ? d_raw : h->d_raw), (const int*)(d_starts ? d_starts : h->d_starts), d_reads ? d_reads : h->d_reads,
+            n_reads, (long long)ev0, n_ev, d_out};
   const long long total = (long long)n_ev * 50;
   hipLaunchKernelGGL(segment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
 }
@@ -1736,11 +1759,156 @@ int nrv_predict_read(nrv_handle* h, const float* sig_ev, const float* feat_ev, i
   return predict_host(h, sig_ev, feat_ev, N, true, p1, p2, a1, a2);
 }
 
+// ---- whole-call raw reads (r06) ----------------------------------------------------------------------------------------
+static int raw_check(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts, const float* feat, int64_t N,
+                     const nrv_read_desc* reads, int n_reads) {
+  if (n_raw < 0 || N < 0 || n_reads < 0 || (n_raw > 0 && !raw) || (N > 0 && (!starts || !reads || !feat || n_reads == 0))) {
+    h->err = "nrv raw reads: bad arguments";
+    return NRV_E_INVALID;
+  }
+  int64_t ev = 0;
+  for (int r = 0; r < n_reads; ++r) {          // descriptors must tile [0, N) in order and stay inside raw
+    const nrv_read_desc& d = reads[r];
+    if (d.ev_off != ev || d.ev_len < 0 || d.raw_off < 0 || d.raw_len < 0 || d.raw_off + d.raw_len > n_raw) {
+      h->err = "nrv raw reads: read descriptors do not tile the event range / exceed the sample array";
+      return NRV_E_INVALID;
+    }
+    ev += d.ev_len;
+  }
+  if (ev != N) { h->err = "nrv raw reads: read descriptors do not cover N events"; return NRV_E_INVALID; }
+  return NRV_OK;
+}
+
+// every stage of a slot's call onto the compute stream: segmentation of the stage's events, then its launch groups
+static int raw_enqueue(nrv_handle* h, nrv_handle::RawSlot& sl) {
+  const int T = h->T;
+  const int stage = stage_windows(h, true);
+  char* const d = sl.d_out + 64;
+  const float* d_feat = (const float*)(sl.d_in + sl.off_feat);
+  for (int64_t s = 0; s < sl.n; s += stage) {
+    const int nb = (int)((sl.n - s < stage) ? (sl.n - s) : stage);
+    launch_segment(h, sl.n_reads, s, nb + T - 1, h->d_sig[0], (const int16_t*)sl.d_in, (const int32_t*)(sl.d_in + sl.off_starts),
+                   (const SegRead*)(sl.d_in + sl.off_reads));
+    const int rc = for_groups(h, nb, [&](int64_t w, int nw) {
+      return run_group(h, h->d_sig[0] + w * kSig, d_feat + (s + w) * kFeat, nw, true,
+                       (float*)d + (s + w) * 6, (float*)(d + sl.rows * 24) + (s + w) * 5, (int8_t*)(d + sl.rows * 44) + (s + w),
+                       (int8_t*)(d + sl.rows * 45) + (s + w), (unsigned*)sl.d_out);
+    });
+    if (rc) return rc;
+  }
+  return NRV_OK;
+}
+
+int nrv_reads_raw_begin(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts,
+                        const float* feat_ev, int64_t N, const nrv_read_desc* reads, int n_reads,
+                        float* p1, float* p2, int8_t* a1, int8_t* a2, int* ticket) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!ticket) { h->err = "nrv_reads_raw_begin: null ticket"; return NRV_E_INVALID; }
+  if ((rc = raw_check(h, raw, n_raw, starts, feat_ev, N, reads, n_reads))) return rc;
+  int k = -1;
+  for (int i = 0; i < 2; ++i) if (!h->raw_slot[i].busy) { k = i; break; }
+  if (k < 0) { h->err = "nrv_reads_raw_begin: two calls are in flight already (collect one with nrv_reads_raw_end)"; return NRV_E_INVALID; }
+  nrv_handle::RawSlot& sl = h->raw_slot[k];
+  const int T = h->T;
+  sl.N = N; sl.n = N - T > 0 ? N - T : 0; sl.n_reads = n_reads;
+  sl.p1 = p1; sl.p2 = p2; sl.a1 = a1; sl.a2 = a2;
+  *ticket = k;
+  if (sl.n == 0) { sl.busy = true; return NRV_OK; }           // nothing to compute: _end returns at once
+  static_assert(sizeof(SegRead) == sizeof(nrv_read_desc), "descriptor layouts must match");
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  sl.off_starts = up((size_t)n_raw * 2);
+  sl.off_reads = sl.off_starts + up((size_t)N * 4);
+  sl.off_feat = sl.off_reads + up((size_t)n_reads * sizeof(SegRead));
+  const size_t in_bytes = sl.off_feat + up((size_t)N * kFeat * 4);
+  sl.rows = ((size_t)sl.n + kRowPad - 1) / kRowPad * kRowPad;
+  const size_t out_bytes = 64 + sl.rows * kOutBytes;
+  if (!sl.ev_in) {
+    HIPCHK(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+  }
+  if (in_bytes > sl.cap_in) {                                   // the slot is free: nothing of it is in flight
+    (void)hipFree(sl.d_in); (void)hipHostFree(sl.pin_in);
+    sl.d_in = sl.pin_in = nullptr; sl.cap_in = 0;
+    const size_t c = in_bytes + in_bytes / 2 + 4096;
+    HIPCHK(h, hipMalloc((void**)&sl.d_in, c));
+    HIPCHK(h, hipHostMalloc((void**)&sl.pin_in, c, hipHostMallocDefault));
+    sl.cap_in = c;
+  }
+  if (out_bytes > sl.cap_out) {
+    (void)hipFree(sl.d_out); (void)hipHostFree(sl.pin_out);
+    sl.d_out = sl.pin_out = nullptr; sl.cap_out = 0;
+    const size_t c = out_bytes + out_bytes / 2 + 4096;
+    HIPCHK(h, hipMalloc((void**)&sl.d_out, c));
+    HIPCHK(h, hipMemset(sl.d_out, 0, 64));                      // the range-guard counter only ever grows
+    HIPCHK(h, hipHostMalloc((void**)&sl.pin_out, c, hipHostMallocDefault));
+    memset(sl.pin_out, 0, 64);
+    sl.cap_out = c;
+    sl.sat_seen = 0;
+  }
+  if ((rc = ensure_workspace(h))) return rc;
+  // inputs -> page-locked staging (a host copy of 92 B per base that overlaps the previous call's kernels) -> ONE upload
+  memcpy(sl.pin_in, raw, (size_t)n_raw * 2);
+  memcpy(sl.pin_in + sl.off_starts, starts, (size_t)N * 4);
+  memcpy(sl.pin_in + sl.off_reads, reads, (size_t)n_reads * sizeof(SegRead));
+  memcpy(sl.pin_in + sl.off_feat, feat_ev, (size_t)N * kFeat * 4);
+  HIPCHK(h, hipMemcpyAsync(sl.d_in, sl.pin_in, in_bytes, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(sl.ev_in, h->copy_stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+  if ((rc = raw_enqueue(h, sl))) return rc;
+  HIPCHK(h, hipEventRecord(sl.ev_done, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, sl.ev_done, 0));
+  HIPCHK(h, hipMemcpyAsync(sl.pin_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, h->d2h_stream));
+  HIPCHK(h, hipEventRecord(sl.ev_out, h->d2h_stream));
+  HIPCHK(h, hipGetLastError());
+  sl.busy = true;
+  return NRV_OK;
+}
+
+int nrv_reads_raw_end(nrv_handle* h, int ticket) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (ticket < 0 || ticket > 1 || !h->raw_slot[ticket].busy) { h->err = "nrv_reads_raw_end: no such call in flight"; return NRV_E_INVALID; }
+  nrv_handle::RawSlot& sl = h->raw_slot[ticket];
+  sl.busy = false;                                              // whatever happens below, the slot is the caller's again
+  if (sl.n == 0) return NRV_OK;
+  HIPCHK(h, hipEventSynchronize(sl.ev_out));
+  if (*(unsigned*)sl.pin_out != sl.sat_seen) {
+    // f16x2 range guard: some stage of this call left the f16 range.  Its inputs are still in the slot: the whole call
+    // again on the f32 kernels, which have no range limit (behind whatever the other slot has enqueued meanwhile).
+    const int h2 = h->h2, split = h->split;
+    h->h2 = 0; h->split = 0;
+    const int rc2 = raw_enqueue(h, sl);
+    h->h2 = h2; h->split = split;
+    if (rc2) return rc2;
+    HIPCHK(h, hipMemcpyAsync(sl.pin_out, sl.d_out, 64 + sl.rows * kOutBytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    sl.sat_seen = *(unsigned*)sl.pin_out;
+    h->sat_reruns += 1;
+  }
+  const char* o = sl.pin_out + 64;
+  const size_t n = (size_t)sl.n;
+  if (sl.p1) memcpy(sl.p1, o, n * 24);
+  if (sl.p2) memcpy(sl.p2, o + sl.rows * 24, n * 20);
+  if (sl.a1) memcpy(sl.a1, o + sl.rows * 44, n);
+  if (sl.a2) memcpy(sl.a2, o + sl.rows * 45, n);
+  return NRV_OK;
+}
+
 int nrv_predict_reads_raw(nrv_handle* h, const int16_t* raw, int64_t n_raw, const int32_t* starts,
                           const float* feat_ev, int64_t N, const nrv_read_desc* reads, int n_reads,
                           float* p1, float* p2, int8_t* a1, int8_t* a2) {
   int rc = check_handle(h);
   if (rc) return rc;
+  // NRV_RAW_STAGED=1: round 5's form (per-stage uploads and downloads through predict_host's staging sets); default since r06:
+  // the whole call at once (nrv_reads_raw_begin + _end).  Same kernels on the same windows: the same bits.
+  static const bool staged = getenv("NRV_RAW_STAGED") && atoi(getenv("NRV_RAW_STAGED")) != 0;
+  if (!staged && !h->raw_slot[0].busy && !h->raw_slot[1].busy) {
+    int t = -1;
+    if ((rc = nrv_reads_raw_begin(h, raw, n_raw, starts, feat_ev, N, reads, n_reads, p1, p2, a1, a2, &t))) return rc;
+    return nrv_reads_raw_end(h, t);
+  }
   if ((rc = upload_raw(h, raw, n_raw, starts, N, reads, n_reads))) return rc;
   return predict_host(h, nullptr, feat_ev, N, true, p1, p2, a1, a2, n_reads);
 }

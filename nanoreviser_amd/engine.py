@@ -31,7 +31,7 @@ SYMBOLS = [
     "nrv_create", "nrv_destroy", "nrv_predict", "nrv_predict_read", "nrv_predict_device",
     "nrv_predict_read_device", "nrv_set_batch", "nrv_get_batch", "nrv_set_stream", "nrv_sync",
     "nrv_prof_enable", "nrv_prof_read", "nrv_kernel_name", "nrv_last_error", "nrv_backend",
-    "nrv_window", "nrv_set_precision", "nrv_get_precision", "nrv_predict_reads_raw", "nrv_segment_reads",
+    "nrv_window", "nrv_set_precision", "nrv_get_precision", "nrv_predict_reads_raw", "nrv_reads_raw_begin", "nrv_reads_raw_end", "nrv_segment_reads",
     "nrv_device_count", "nrv_saturated", "nrv_prof_overhead",
 ]
 
@@ -132,6 +132,10 @@ def load_library(path: Optional[str] = None):
     lib.nrv_device_count.argtypes = []
     i16p, i32p, rdp = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(_ReadDesc)
     lib.nrv_predict_reads_raw.argtypes = [vp, i16p, C.c_int64, i32p, fp, C.c_int64, rdp, C.c_int, fp, fp, i8p, i8p]
+    lib.nrv_reads_raw_begin.argtypes = [vp, i16p, C.c_int64, i32p, fp, C.c_int64, rdp, C.c_int, fp, fp, i8p, i8p, C.POINTER(C.c_int)]
+    lib.nrv_reads_raw_begin.restype = C.c_int
+    lib.nrv_reads_raw_end.argtypes = [vp, C.c_int]
+    lib.nrv_reads_raw_end.restype = C.c_int
     lib.nrv_segment_reads.argtypes = [vp, i16p, C.c_int64, i32p, C.c_int64, rdp, C.c_int, fp]
     lib.nrv_prof_overhead.argtypes = [vp, C.POINTER(C.c_double)]
     lib.nrv_saturated.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -317,6 +321,24 @@ class Reviser:
             feat.ctypes.data_as(fp), N, descs, nr,
             p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p)))
         return p1, p2, a1, a2
+
+    def begin_packed_raw(self, packed):
+        """First half of `run_packed_raw` (nrv_reads_raw_begin): the inputs are copied and the whole call is enqueued; returns a
+        ticket for `end_packed_raw`.  At most two calls in flight; the OUTPUT arrays of `packed` must stay alive until the end."""
+        raw, st, feat, descs, nr, N, (p1, p2, a1, a2) = packed
+        fp, i8p = C.POINTER(C.c_float), C.POINTER(C.c_int8)
+        t = C.c_int(-1)
+        self._check(self._lib.nrv_reads_raw_begin(
+            self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), raw.size, st.ctypes.data_as(C.POINTER(C.c_int32)),
+            feat.ctypes.data_as(fp), N, descs, nr,
+            p1.ctypes.data_as(fp), p2.ctypes.data_as(fp), a1.ctypes.data_as(i8p), a2.ctypes.data_as(i8p), C.byref(t)))
+        return t.value, (p1, p2, a1, a2)
+
+    def end_packed_raw(self, ticket):
+        """Second half: waits for the call `ticket` names and returns its (p1, p2, a1, a2)."""
+        t, out = ticket
+        self._check(self._lib.nrv_reads_raw_end(self._h, t))
+        return out
 
     def predict_reads_raw(self, raws, starts, feats, shifts, scales):
         """Reads given as raw int16 samples (from their first event on), int32 event starts, (N,6)

@@ -65,6 +65,46 @@ class PackedEcho(EchoEngine):
         return p1, p2, a1, a2
 
 
+class PipelinedEcho(PackedEcho):
+    """PackedEcho with the two-halves surface of engine.Reviser (begin_packed_raw / end_packed_raw, r06): what the command
+    line pipelines two deep.  Keeps the contract of the native handle: at most two calls in flight, a ticket is good once,
+    nothing else may run on the engine between a call's halves.  `fail_in_end`: the call whose first event matches
+    fail_marker fails in its SECOND half (the first half only enqueues)."""
+
+    def __init__(self, fail_marker=None, fail_in_end=False):
+        super().__init__(None if fail_in_end else fail_marker)
+        self.end_marker = fail_marker if fail_in_end else None
+        self.flight, self.max_in_flight, self.begun, self.violations = {}, 0, 0, []
+
+    def begin_packed_raw(self, packed):
+        if len(self.flight) >= 2:
+            raise RuntimeError("two calls are in flight already")
+        out = PackedEcho.run_packed_raw(self, packed)      # raises here for a fail_marker of the first half
+        self.begun += 1
+        self.flight[self.begun] = (packed[2][0].copy() if len(packed[2]) else None, out)
+        self.max_in_flight = max(self.max_in_flight, len(self.flight))
+        return self.begun, out
+
+    def end_packed_raw(self, ticket):
+        t, out = ticket
+        first, out2 = self.flight.pop(t)                   # KeyError: a ticket used twice
+        if t != min([t] + list(self.flight)):
+            self.violations.append(("out of order", t))
+        if self.end_marker is not None and first is not None and np.array_equal(first, self.end_marker):
+            raise RuntimeError("injected engine failure in the second half")
+        return out
+
+    def run_packed_raw(self, packed):
+        if self.flight:
+            self.violations.append(("synchronous call between the halves of another", len(self.flight)))
+        return super().run_packed_raw(packed)
+
+    def predict_read(self, sig_ev, feat_ev):
+        if self.flight:
+            self.violations.append(("per-read call between the halves of another", len(self.flight)))
+        return super().predict_read(sig_ev, feat_ev)
+
+
 def echo_factory(args, device):
     return EchoEngine()
 

@@ -536,3 +536,43 @@ def test_output_directory_probe_warns_when_the_filesystem_is_too_slow(tmp_path, 
     assert cli.check_output_rate(args, 8, 10 ** 5, msgs.append) == 1e6 and len(msgs) == 1
     monkeypatch.setenv("NRV_OUTPUT_PROBE", "0")
     assert cli.check_output_rate(args, 8, 10 ** 5, msgs.append) is None
+
+
+def test_device_calls_are_pipelined_two_deep_and_give_the_same_files(tmp_path, monkeypatch):
+    """r06: with the native host stage the engine thread enqueues bundle k+1 (begin_packed_raw) before it collects bundle k
+    (end_packed_raw).  Same files as one call at a time (NRV_CLI_PIPELINE=0), two calls in flight at most, collected in order,
+    nothing else on the engine between a call's halves; a call that fails in its SECOND half is isolated read by read
+    and only the failing read is written unrevised."""
+    import shutil
+    from nanoreviser_amd import hostlib
+    from echo_engine import PipelinedEcho
+    if hostlib.load() is None:
+        pytest.skip("libnanorev_host.so not built")
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    for i in range(40):
+        shutil.copy(src[i % 2], d / f"r{i:02d}.fast5")
+    monkeypatch.setenv("NRV_CLI_GROUPS", "1")                           # small device calls: many bundles
+    outs, engs = {}, {}
+    for tag, env in (("pipelined", "1"), ("one_at_a_time", "0")):
+        monkeypatch.setenv("NRV_CLI_PIPELINE", env)
+        eng = engs[tag] = PipelinedEcho()
+        out = str(tmp_path / tag) + "/"
+        assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "3"], reviser_factory=lambda a, dev: eng) == 0
+        outs[tag] = {f: open(out + f, "rb").read() for f in sorted(os.listdir(out))}
+    assert outs["pipelined"] == outs["one_at_a_time"] and len(outs["pipelined"]) == 41
+    assert engs["pipelined"].begun >= 5 and engs["pipelined"].max_in_flight == 2 and not engs["pipelined"].flight
+    assert engs["one_at_a_time"].begun == 0 and engs["one_at_a_time"].calls >= 5
+    assert not engs["pipelined"].violations, engs["pipelined"].violations
+    # a bundle whose SECOND half fails: its reads are retried one by one, the marked read alone falls back
+    _, _, rt0 = load_read("_".join(os.path.basename(src[0]).split("_")[-3:-1]))
+    monkeypatch.setenv("NRV_CLI_PIPELINE", "1")
+    eng = PipelinedEcho(fail_marker=rt0.feat_ev[0], fail_in_end=True)
+    eng_probe = EchoEngine(fail_marker=rt0.feat_ev[0])                  # the per-read retry fails for that read too
+    eng.predict_read = lambda s, f: (eng.violations.append("retry between halves") if eng.flight else None) or EchoEngine.predict_read(eng_probe, s, f)
+    out = str(tmp_path / "fail") + "/"
+    assert cli.main(["-d", str(d), "-o", out, "-S", "ecoli", "--thread", "3"], reviser_factory=lambda a, dev: eng) == 0
+    failed = open(out + "failed_reads.txt").read().split()
+    assert failed and all(int(f[1:3]) % 2 == 0 for f in failed)          # only copies of the marked read (src[0])
+    assert len([f for f in os.listdir(out) if f.endswith("_out.fasta")]) == 40 and not eng.violations, eng.violations

@@ -104,3 +104,47 @@ def test_raw_read_call_of_five_stages_equals_shorter_calls(species_models):
         assert np.array_equal(t[N5:N5 + n5].view(np.uint8), f.view(np.uint8))
     assert rv.saturated() == (0, 0)
     rv.close()
+
+
+def test_two_raw_read_calls_in_flight_equal_the_calls_one_by_one(species_models):
+    """nrv_reads_raw_begin / _end (r06): a raw-read call goes up in one transfer, all its stages are enqueued at once, and a
+    second call may be enqueued before the first is collected.  Three different bundles, two in flight at any time, must come
+    back with the bits of the same bundles run one by one - and with the bits of the per-event entry point (nrv_predict_read:
+    host-side arrays through the staged pipeline) on the device's own segmentation of the same reads.  A third call in
+    flight is refused, a ticket is good for one _end."""
+    import bench
+    from nanoreviser_amd.engine import Reviser
+    m1, m2 = species_models["human"]
+    reads = bench.fixture_reads()
+
+    def pack(rs):
+        return [[r.raw for r in rs], [r.starts for r in rs], [r.feat_ev for r in rs], [r.shift for r in rs], [r.scale for r in rs]]
+    rv = Reviser(m1, m2, precision="f16x2")
+    bundles = [reads[0:3], reads[2:5], reads + reads[:2]]
+    one_by_one = [[x.copy() for x in rv.predict_reads_raw(*pack(b))] for b in bundles]
+    pk = [rv.pack_reads_raw(*pack(b), rv.T) for b in bundles]
+    tA = rv.begin_packed_raw(pk[0])
+    tB = rv.begin_packed_raw(pk[1])
+    with pytest.raises(RuntimeError, match="two calls are in flight"):
+        rv.begin_packed_raw(rv.pack_reads_raw(*pack(bundles[2]), rv.T))
+    outA = rv.end_packed_raw(tA)
+    tC = rv.begin_packed_raw(pk[2])
+    outB = rv.end_packed_raw(tB)
+    outC = rv.end_packed_raw(tC)
+    with pytest.raises(RuntimeError, match="no such call in flight"):
+        rv.end_packed_raw(tC)
+    for got, want in zip((outA, outB, outC), one_by_one):
+        for g, w in zip(got, want):
+            assert g.shape == w.shape and np.array_equal(g.view(np.uint8), w.view(np.uint8))
+    # the per-event entry point on the same reads' device-cut windows: another pipeline, the same kernels on the same windows
+    b = bundles[1]
+    sig_ev = rv.segment_reads(*[pack(b)[i] for i in (0, 1, 3, 4)])
+    feat = np.concatenate([r.feat_ev for r in b])
+    per_event = rv.predict_read(sig_ev, feat)
+    for g, w in zip(one_by_one[1], per_event):
+        assert np.array_equal(g.view(np.uint8), w.view(np.uint8))
+    assert rv.saturated() == (0, 0)
+    # an empty call and a call shorter than a window go through both halves too
+    short = rv.pack_reads_raw([reads[0].raw[:200]], [reads[0].starts[:5]], [reads[0].feat_ev[:5]], [reads[0].shift], [reads[0].scale], rv.T)
+    assert all(len(x) == 0 for x in rv.end_packed_raw(rv.begin_packed_raw(short)))
+    rv.close()
