@@ -376,32 +376,41 @@ def test_small_groups_coalesced_or_on_lanes_bit_identical(species_models, monkey
     feat_ev = torch.rand(N, 6, device="cuda", generator=g)
 
     def outs(k):
-        return (torch.empty(k, 6, device="cuda"), torch.empty(k, 5, device="cuda"),
-                torch.empty(k, dtype=torch.int8, device="cuda"), torch.empty(k, dtype=torch.int8, device="cuda"))
+        # sentinels, not torch.empty: a row the engine does not write must not pass because the allocator handed back the
+        # block an earlier, identical run had filled (r06: one unexplained failure of this test in ~12 runs of the suite)
+        return (torch.full((k, 6), float("nan"), device="cuda"), torch.full((k, 5), float("nan"), device="cuda"),
+                torch.full((k,), -7, dtype=torch.int8, device="cuda"), torch.full((k,), -7, dtype=torch.int8, device="cuda"))
 
     def run(rv):
         w, r = outs(n), outs(N - T)
+        torch.cuda.synchronize()
         rv.predict_device(sig.data_ptr(), feat.data_ptr(), n, *[x.data_ptr() for x in w])
         rv.predict_read_device(sig_ev.data_ptr(), feat_ev.data_ptr(), N, *[x.data_ptr() for x in r])
         rv.sync()
         torch.cuda.synchronize()
         return w + r
 
+    def _where(x, y):
+        bad = (x != y) if x.dim() == 1 else (x != y).any(1)
+        idx = torch.nonzero(bad).flatten()
+        return f"{tuple(x.shape)}: {idx.numel()} rows differ, first {idx[:8].tolist()}, last {idx[-4:].tolist()}; x {x[idx[:2]].tolist()} y {y[idx[:2]].tolist()}"
+
     ref_rv = Reviser(m1, m2, batch=4096)
     ref = run(ref_rv)
     ref_rv.close()
+    assert not any(torch.isnan(x).any() for x in ref[:2] + ref[4:6]) and all((x != -7).all() for x in ref[2:4] + ref[6:8])
     for batch in (512, 1000):                         # coalesced
         rv = Reviser(m1, m2, batch=batch)
         assert rv.batch == batch
         for x, y in zip(ref, run(rv)):
-            assert torch.equal(x, y), batch
+            assert torch.equal(x, y), (batch, _where(x, y))
         rv.close()
     monkeypatch.setenv("NRV_COALESCE", "0")
     for batch in (512, 992, 1000, 2048):              # lanes; 1000: not whole row tiles, stays on one stream
         rv = Reviser(m1, m2, batch=batch)
         for _ in range(2):
             for x, y in zip(ref, run(rv)):
-                assert torch.equal(x, y), batch
+                assert torch.equal(x, y), (batch, _where(x, y))
         rv.close()
     monkeypatch.setenv("NRV_LANES", "0")
     rv = Reviser(m1, m2, batch=512)
