@@ -783,12 +783,26 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_h
         raws = [[r.raw for r in reads], [r.starts for r in reads], [r.feat_ev for r in reads],
                 [r.shift for r in reads], [r.scale for r in reads]]
         dth = _time_calls(lambda: rv.predict_reads_raw(*raws), lambda: None, max(2, reps // 4))
+        # ... and the same entry point as the command line drives it since r06: two calls in flight (nrv_reads_raw_begin / _end),
+        # call k+1 enqueued before call k is collected
+        npipe = max(4, reps // 4)
+        packs = [rv.pack_reads_raw(*raws, a.T) for _ in range(2)]
+        rv.end_packed_raw(rv.begin_packed_raw(packs[0]))                                   # warm
+        t0 = time.perf_counter()
+        tk = rv.begin_packed_raw(packs[0])
+        for i in range(1, npipe):
+            nxt = rv.begin_packed_raw(packs[i & 1])
+            rv.end_packed_raw(tk)
+            tk = nxt
+        rv.end_packed_raw(tk)
+        dtp = (time.perf_counter() - t0) / npipe
         cfg[name] = {"config": f"{sp} weights, T={a.T}, batch={batch} windows per launch group, the five fixture reads "
                                f"({nb} bases) x {reps} = {5 * reps} reads; fast5 parsing excluded",
                      "reads": 5 * reps, "bases": n * reps, "seconds_device_resident": dt * reps,
                      "reads_host_inclusive": 5 * max(2, reps // 4),
                      "bases_per_s_device_resident": n / dt,
                      "bases_per_s_host_inclusive_raw_reads": n / dth,
+                     "bases_per_s_host_inclusive_raw_reads_pipelined": n / dtp,
                      "achieved_tflops": n * FLOP_PER_BASE_DEDUP[11] / dt / 1e12}
         rv.close()
     out["configs"] = cfg
@@ -796,6 +810,11 @@ def extras(args, torch, dev, local_rank, m1, m2, sig, rd, dev_ms_per_step, cli_h
                                    "bytes_per_base_over_pcie": 46 + 46,
                                    "vs_device_resident": cfg["C3"]["bases_per_s_host_inclusive_raw_reads"]
                                    / cfg["C3"]["bases_per_s_device_resident"]}
+    hi["nrv_reads_raw_begin_end"] = {"bases_per_s": cfg["C3"]["bases_per_s_host_inclusive_raw_reads_pipelined"],
+                                     "bytes_per_base_over_pcie": 46 + 46, "calls_in_flight": 2,
+                                     "vs_device_resident": cfg["C3"]["bases_per_s_host_inclusive_raw_reads_pipelined"]
+                                     / cfg["C3"]["bases_per_s_device_resident"],
+                                     "what": "the same calls with call k+1 enqueued before call k is collected (how the command line drives the engine)"}
     return out
 
 
