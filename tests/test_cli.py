@@ -489,6 +489,40 @@ def test_cli_end_to_end_on_gpu(tmp_path, species_models):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+def test_pipelined_device_calls_write_the_files_of_one_call_at_a_time_on_gpu(tmp_path, monkeypatch, fmt):
+    """The REAL engine: 60 reads (all five fixture reads, interleaved) in small device calls, pipelined two deep
+    (nrv_reads_raw_begin / _end; the default) against one call at a time (NRV_CLI_PIPELINE=0) against round 5's staged calls
+    (NRV_RAW_STAGED is read once per process, so that form runs as a child): the same bytes in every file, FASTA and FASTQ
+    (the qualities come from p1 / p2: every output of the call is covered)."""
+    import shutil
+    import subprocess
+    import sys
+    src = sorted(glob.glob(os.path.join(FAST5, "*.fast5")) + glob.glob(os.path.join(GOLD, "fast5_more", "*.fast5")))
+    d = tmp_path / "in"
+    d.mkdir()
+    for i in range(60):
+        shutil.copy(src[(i * 3) % len(src)], d / f"p{i:02d}.fast5")
+    monkeypatch.setenv("NRV_CLI_GROUPS", "4")                           # ~4 reads per call: fifteen calls, ragged last groups
+    outs = {}
+    for tag, env in (("pipelined", "1"), ("one_at_a_time", "0")):
+        monkeypatch.setenv("NRV_CLI_PIPELINE", env)
+        out = str(tmp_path / tag) + "/"
+        assert cli.main(["-d", str(d), "-o", out, "-S", "human", "-F", fmt, "--thread", "4", "--gpus", "1"]) == 0
+        outs[tag] = {f: open(out + f, "rb").read() for f in sorted(os.listdir(out))}
+    out = str(tmp_path / "staged") + "/"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "NanoReviser.py"), "-d", str(d), "-o", out, "-S", "human", "-F", fmt,
+                        "--thread", "4", "--gpus", "1"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, NRV_RAW_STAGED="1", NRV_CLI_PIPELINE="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs["staged"] = {f: open(out + f, "rb").read() for f in sorted(os.listdir(out))}
+    assert len(outs["pipelined"]) == 61 and outs["pipelined"]["failed_reads.txt"] == b""
+    assert outs["pipelined"] == outs["one_at_a_time"] == outs["staged"]
+    assert len({v for k, v in outs["pipelined"].items() if k.startswith("p0")}) >= 5   # (the reads do differ)
+
+
+@pytest.mark.gpu
 def test_script_with_parser_pool_is_quiet_and_complete(tmp_path):
     """`python NanoReviser.py` as a child process with a parser pool (>= 4 files, --thread 4): exit code 0, nothing on
     stderr (the script leaves with os._exit once main() has returned - the pool must have been shut down in order, or
