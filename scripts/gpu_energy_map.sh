@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL (r05): -DNRV_LSTM_MAP was removed from the sources in round 6; the result is in profiles/r05_energy_map.json.
 # r05 energy experiment (VERDICT r04 #4a): forward and backward workgroup of a row block on the SAME XCD (-DNRV_LSTM_MAP=1) against
 # the default placement, on lstm_h2w_kernel (192->128) and lstm_h2s_kernel (256->64): microseconds (same process), socket power and
 # shader clock (one launch looped for 4 s), FETCH_SIZE / WRITE_SIZE / TCC hits and misses (rocprofv3 --pmc, separate passes).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a step of lstm_h2s_kernel (the 256->64 layer; the 192->128 one with -DNRV_L3_WS=0) spends its cycles: reads the s_memtime stamps of the diagnostic build
+"""Where a step of lstm_h2s_kernel (the 256->64 layer; until round 5 also the 192->128 one, with -DNRV_L3_WS=0: that switch is gone since r06) spends its cycles: reads the s_memtime stamps of the diagnostic build
 (tools/lstm_exp.sh stamp -> csrc/exp/libnanorev_hip_stamp.so, -DNRV_STAMP=1) after a few hundred bench steps on the
 bench's own synthetic windows (the product's data, so the product's clock).  Read SHARES, not lengths.
   python3 scripts/gpu_stamps.py [lib.so] > gpurun_out/stamps.json
@@ -51,7 +51,7 @@ def med(x):
 
 out = {}
 # The 192->128 layer runs lstm_h2w_kernel by default (its stamps: scripts/gpu_stamps_w.py); STAMP_L3_H2S=1 reads its
-# region in this layout too, for a library built with -DNRV_L3_WS=0.
+# region in this layout too, for a library built with -DNRV_L3_WS=0 (rounds 4-5 only).
 layers = (("lstm3 192->128", 6, 4), ("lstm4 256->64", 8, 2))
 for li, (name, kk_in, kk_rec) in enumerate(layers):
     if li == 0 and os.environ.get("STAMP_L3_H2S", "0") != "1":

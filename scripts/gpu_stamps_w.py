@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a step of lstm_h2w_kernel (eight waves, two groups) spends its cycles: reads the s_memtime stamps of a
-diagnostic build (-DNRV_STAMP=1 -DNRV_L3_WS=1) after a few hundred bench steps on the bench's synthetic windows.
+diagnostic build (-DNRV_STAMP=1) after a few hundred bench steps on the bench's synthetic windows.
   python3 scripts/gpu_stamps_w.py lib.so > gpurun_out/stamps_w.json
 Slots per (workgroup, wave, loop iteration): 0 top (second half of step s) | 1 A: gates done, B: in() done |
 2 second half done | 3 behind barrier 2 | 4 rec() starts | 5 rec() done | 6 behind barrier 1 | 7..11 in() k blocks 1..5 start |

@@ -5,8 +5,9 @@
 #   tools/lstm_exp.sh stamp                      -> exp/libnanorev_hip_stamp.so   -DNRV_STAMP=1: s_memtime stamps at the phase
 #                                                   edges of lstm_h2s_kernel (scripts/gpu_stamps.py) and lstm_h2w_kernel
 #                                                   (scripts/gpu_stamps_w.py)
-#   tools/lstm_exp.sh D:name:-DNRV_X=1,-DNRV_Y=2 -> exp/libnanorev_hip_name.so    any -D flags (e.g. -DNRV_EXP=<bits>: parts of
-#                                                   cnn_r_kernel compiled out, results WRONG, timing only)
+#   tools/lstm_exp.sh D:name:-DNRV_X=1,-DNRV_Y=2 -> exp/libnanorev_hip_name.so    any -D flags (round 6 removed the experiment switches
+#                                                   from the sources: a knock-out is a temporary #if block now, built this way,
+#                                                   timed by scripts/gpu_variants.py and never committed - HISTORY.md r06)
 # FAST=1 adds -DNRV_DEV_FAST (f16x2 mode with hard_sigmoid only: half the compile time; never the product).
 cd "$(dirname "$0")/../nanoreviser_amd/csrc" || exit 1
 mkdir -p exp
