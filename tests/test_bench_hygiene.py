@@ -121,3 +121,22 @@ def test_scratch_base_prefers_a_tmpfs_and_can_be_overridden(monkeypatch, tmp_pat
     monkeypatch.delenv("NRV_BENCH_SCRATCH")
     base, what = bench.scratch_base()
     assert (base == "/dev/shm" and "tmpfs" in what) or (base is None and "default temporary directory" in what)
+
+
+def test_round6_line_helpers():
+    """r06 additions of the bench line that need no GPU: the committed rocprof trace's duration of the dominant kernel (what
+    `roofline.frac_rocprof` is computed from) and the device identity that decides whether N ranks ran on N devices."""
+    for prec in ("f16x2", "f32"):
+        us, src = bench.rocprof_duration_us(prec)
+        assert us is not None and 50 < us < 2000 and src.endswith(f"_kernel_stats_timed_region_{prec}.csv"), (prec, us, src)
+        fl = bench.flop_lstm3_launch(13, 4096, executed=True)
+        frac = fl / (us * 1e-6) / 1e12 / bench.mode_peak(prec)[0]
+        assert 0.3 < frac < 1.0, (prec, frac)
+    us, why = bench.rocprof_duration_us("f16x2", profiles_dir=os.path.join(ROOT, "tests"))     # no trace there: says so
+    assert us is None and "no committed kernel trace" in why
+    a = {"pci": "0000:72:00", "uuid": "u1", "device": 0}
+    b = {"pci": "0000:73:00", "uuid": "u2", "device": 1}
+    assert bench.device_key(a) != bench.device_key(b) and bench.device_key(a) == bench.device_key(dict(a, device=5))
+    # a runtime that reports no identity at all must never make N devices look like one
+    z0, z1 = {"pci": "0000:00:00", "uuid": "", "device": 0}, {"pci": "0000:00:00", "uuid": "", "device": 1}
+    assert bench.device_key(z0) != bench.device_key(z1)
