@@ -1856,7 +1856,10 @@ int nrv_reads_raw_begin(nrv_handle* h, const int16_t* raw, int64_t n_raw, const 
   HIPCHK(h, hipMemcpyAsync(sl.d_in, sl.pin_in, in_bytes, hipMemcpyHostToDevice, h->copy_stream));
   HIPCHK(h, hipEventRecord(sl.ev_in, h->copy_stream));
   HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
-  if ((rc = raw_enqueue(h, sl))) return rc;
+  if ((rc = raw_enqueue(h, sl))) {
+    (void)hipStreamSynchronize(h->stream);                      // part of the call may be enqueued: nothing of it may outlive the slot
+    return rc;
+  }
   HIPCHK(h, hipEventRecord(sl.ev_done, h->stream));
   HIPCHK(h, hipStreamWaitEvent(h->d2h_stream, sl.ev_done, 0));
   HIPCHK(h, hipMemcpyAsync(sl.pin_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, h->d2h_stream));
